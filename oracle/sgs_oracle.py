@@ -1,0 +1,451 @@
+"""CPU oracle for the SGS-GNN hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; the shipped package (sgs-gnn_amd/) never does and fails loudly without its HIP
+library.  Everything here is a plain-PyTorch (CPU, fp32 or fp64) restatement of the
+reference's algorithm for one hybrid / straight-through / two-pass training step.  Each
+function cites the reference lines it follows (paths relative to /root/reference).
+
+Pinning status (see DESIGN.md "Oracle"):
+  * sampler (`gumbel_softmax_sampling`, prior draw, `random_edge_sampling`): pinned
+    against the reference's own sampling.py imported unmodified in the build container
+    (tests/golden/gen_golden.py -> tests/golden/sampler_*.pt).
+  * edge scorers, pipelines, losses, gate: pinned against the reference's own model.py /
+    training_*.py / utils.py run in the build container with ONLY the third-party
+    `torch_geometric.nn.GCNConv` layer substituted (PyG is not installable here).
+  * GCNConv / gcn_norm / GAT numerics themselves (torch_geometric==2.3.1, not vendored
+    in the reference, which holds no tests for them): PARITY UNPINNED.  They are
+    restated from PyG's documented semantics and cross-checked only against an
+    independent dense fp64 formula D^-1/2 (A_w + I) D^-1/2 X W^T + b.
+
+Randomness is always an explicit input (`noise`, dropout masks) so that the HIP path and
+the oracle can be fed identical bits; `torch.multinomial(s, q, replacement=False)` is an
+exponential race `topk(s / Exp(1))`, which is what `exp_race_topq` restates.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+EPS_SAMPLER = 1e-12  # sampling.py:92
+
+
+# --------------------------------------------------------------------------------------
+# prior (datasets.py:141-156 `add_degree`)
+# --------------------------------------------------------------------------------------
+def add_degree_prior(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """`data.prob` as datasets.py:141-156 builds it.
+
+    prob_e = softmax_e( E^-1/2 / (colcount[row_e] + rowcount[col_e] + 1e-10) ).
+    (deg_in = 1/colcount, deg_out = 1/rowcount, prob = 1/deg_in[row] + 1/deg_out[col].)
+    The reference evaluates this on the row-sorted COO; for a row-sorted `edge_index`
+    (PyG datasets, `to_undirected`) the two orders coincide.
+    """
+    row, col = edge_index[0], edge_index[1]
+    E = edge_index.shape[1]
+    rowcount = torch.bincount(row, minlength=num_nodes).to(torch.float32)
+    colcount = torch.bincount(col, minlength=num_nodes).to(torch.float32)
+    deg_in = 1.0 / colcount
+    deg_out = 1.0 / rowcount
+    prob = (1.0 / deg_in[row]) + (1.0 / deg_out[col])
+    prob = 1.0 / (prob + 1e-10)
+    return F.softmax(prob * E ** -0.5, dim=0)
+
+
+# --------------------------------------------------------------------------------------
+# sampler (sampling.py:91-155, training_hybrid.py:46-48)
+# --------------------------------------------------------------------------------------
+def exp_race_topq(s: torch.Tensor, noise: torch.Tensor, q: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """`torch.multinomial(s, q, replacement=False)` given its Exp(1) draws.
+
+    ATen's no-replacement path is `topk(s / q_noise, q)` with q_noise ~ Exp(1)
+    (verified bit-for-bit against torch.multinomial under a shared generator state in
+    tests/test_oracle_golden.py).  `topk` leaves ties unspecified; the contract this
+    repo fixes is "lowest edge id wins", i.e. a stable descending sort.
+    Returns (keys, idx) with idx in race order (largest key first).
+    """
+    keys = s / noise
+    order = torch.sort(keys, descending=True, stable=True).indices
+    return keys, order[:q]
+
+
+def sampler_keys(edge_probs: torch.Tensor, prior: Optional[torch.Tensor], c: float,
+                 istest: bool, Z: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """`samples` of sampling.py:93-95.  Z (the fp32 value of edge_probs.sum()) may be
+    supplied so that a differently-ordered reduction can be replayed bit-exactly."""
+    Zs = edge_probs.sum() if Z is None else Z
+    samples = edge_probs / (Zs + EPS_SAMPLER)
+    if not istest:
+        samples = (1 - c) * samples + c * prior
+    return samples, Zs
+
+
+def gumbel_softmax_sampling(prior: Optional[torch.Tensor], edge_probs: torch.Tensor, q: int,
+                            degree_bias_coef: float = 0.3, istest: bool = False,
+                            noise: Optional[torch.Tensor] = None, Z: Optional[torch.Tensor] = None):
+    """sampling.py:91-155 with the multinomial's noise made explicit.
+
+    Returns (mask [E] bool, weights [q] float in original edge order, clamped to [0,1],
+    autograd-connected to edge_probs exactly as the reference: p * ((one_hot - s).detach() + s)).
+    """
+    samples, _ = sampler_keys(edge_probs, prior, degree_bias_coef, istest, Z)
+    _, sampled_edges = exp_race_topq(samples.detach(), noise, q)
+    one_hot = torch.zeros_like(samples)
+    one_hot.scatter_(0, sampled_edges, 1.0)
+    straight_through = (one_hot - samples).detach() + samples
+    weighted = edge_probs * straight_through
+    indexs = one_hot.bool()
+    return indexs, weighted[indexs].clamp(0.0, 1.0)
+
+
+def prior_draw(prob: torch.Tensor, noise: torch.Tensor, q: int) -> torch.Tensor:
+    """training_hybrid.py:46-47: softmax(batch.prob) then multinomial.  Returns the drawn
+    edge ids in race order (the reference's `random_edge_sample`)."""
+    random_samples = F.softmax(prob, dim=-1)
+    _, idx = exp_race_topq(random_samples, noise, q)
+    return idx
+
+
+def random_edge_sampling(edge_index: torch.Tensor, q: int, perm: torch.Tensor) -> torch.Tensor:
+    """sampling.py:159-163 with the permutation explicit."""
+    return edge_index[:, perm[:q]]
+
+
+# --------------------------------------------------------------------------------------
+# GCN layer  (torch_geometric 2.3.1 GCNConv / gcn_norm; PARITY UNPINNED, see header)
+# --------------------------------------------------------------------------------------
+def add_remaining_self_loops(edge_index, edge_weight, fill_value, num_nodes):
+    """PyG 2.3.1 utils.add_remaining_self_loops: drop every (i,i), append one loop per
+    node whose weight is an existing loop's weight (last one wins) or `fill_value`."""
+    mask = edge_index[0] != edge_index[1]
+    loop_index = torch.arange(num_nodes, dtype=edge_index.dtype, device=edge_index.device)
+    loop_index = loop_index.unsqueeze(0).repeat(2, 1)
+    loop_attr = edge_weight.new_full((num_nodes,), fill_value)
+    inv = ~mask
+    loop_attr = loop_attr.index_put((edge_index[0][inv],), edge_weight[inv])
+    ew = torch.cat([edge_weight[mask], loop_attr], dim=0)
+    ei = torch.cat([edge_index[:, mask], loop_index], dim=1)
+    return ei, ew
+
+
+def gcn_norm(edge_index, edge_weight, num_nodes, dtype=torch.float32):
+    """PyG 2.3.1 gcn_norm (add_self_loops=True, flow source_to_target)."""
+    if edge_weight is None:
+        edge_weight = torch.ones(edge_index.shape[1], dtype=dtype, device=edge_index.device)
+    ei, ew = add_remaining_self_loops(edge_index, edge_weight, 1.0, num_nodes)
+    row, col = ei[0], ei[1]
+    deg = torch.zeros(num_nodes, dtype=ew.dtype).index_add(0, col, ew)
+    dis = deg.pow(-0.5)
+    dis = dis.masked_fill(dis == float("inf"), 0.0)
+    return ei, dis[row] * ew * dis[col]
+
+
+def gcn_conv(x, edge_index, edge_weight, weight, bias):
+    """GCNConv.forward: lin (no bias) -> gcn_norm -> scatter-add of w_e * x_src at dst -> + bias.
+    (model.py:94-95,151-153 construct it)"""
+    N = x.shape[0]
+    ei, w = gcn_norm(edge_index, edge_weight, N, dtype=x.dtype)
+    xl = x @ weight.t()
+    msg = w.unsqueeze(1) * xl[ei[0]]
+    out = torch.zeros(N, weight.shape[0], dtype=x.dtype).index_add(0, ei[1], msg)
+    return out + bias
+
+
+def gcn_dense_reference(x, edge_index, edge_weight, weight, bias):
+    """Independent dense restatement D^-1/2 (A_w + I') D^-1/2 X W^T + b used to
+    cross-check gcn_conv (fp64 in tests).  A_w[dst, src] accumulates non-loop weights;
+    the loop weight is an existing loop's weight (last wins) or 1."""
+    N = x.shape[0]
+    if edge_weight is None:
+        edge_weight = torch.ones(edge_index.shape[1], dtype=x.dtype)
+    A = torch.zeros(N, N, dtype=x.dtype)
+    loops = torch.ones(N, dtype=x.dtype)
+    for e in range(edge_index.shape[1]):
+        s, d = int(edge_index[0, e]), int(edge_index[1, e])
+        if s == d:
+            loops[s] = edge_weight[e]
+        else:
+            A[d, s] += edge_weight[e]
+    A = A + torch.diag(loops)
+    deg = A.sum(dim=1)
+    dis = deg.pow(-0.5)
+    dis[torch.isinf(dis)] = 0
+    return (dis[:, None] * A * dis[None, :]) @ (x @ weight.t()) + bias
+
+
+# --------------------------------------------------------------------------------------
+# GAT layer (PyG 2.3.1 GATConv, heads=1, concat; PARITY UNPINNED)
+# --------------------------------------------------------------------------------------
+def gat_conv(x, edge_index, lin_w, att_src, att_dst, bias, negative_slope=0.2, att_mask=None, p=0.0):
+    """GATConv(heads=1): x' = x W^T; alpha_e = leaky_relu(a_s.x'_src + a_d.x'_dst);
+    self loops are removed then one per node added; softmax over each node's in-edges;
+    (attention dropout via explicit keep-mask `att_mask` scaled by 1/(1-p));
+    out_i = sum_e alpha_e x'_src + bias."""
+    N = x.shape[0]
+    keep = edge_index[0] != edge_index[1]
+    loops = torch.arange(N, dtype=edge_index.dtype).unsqueeze(0).repeat(2, 1)
+    ei = torch.cat([edge_index[:, keep], loops], dim=1)
+    xl = x @ lin_w.t()
+    a_s = (xl * att_src).sum(-1)
+    a_d = (xl * att_dst).sum(-1)
+    alpha = F.leaky_relu(a_s[ei[0]] + a_d[ei[1]], negative_slope)
+    amax = torch.full((N,), -float("inf"), dtype=x.dtype).scatter_reduce(0, ei[1], alpha, "amax")
+    ex = (alpha - amax[ei[1]]).exp()
+    den = torch.zeros(N, dtype=x.dtype).index_add(0, ei[1], ex)
+    alpha = ex / (den[ei[1]] + 1e-16)
+    if att_mask is not None:
+        alpha = alpha * att_mask / (1.0 - p)
+    out = torch.zeros(N, xl.shape[1], dtype=x.dtype).index_add(0, ei[1], alpha.unsqueeze(1) * xl[ei[0]])
+    return out + bias
+
+
+# --------------------------------------------------------------------------------------
+# dropout with explicit keep-masks
+# --------------------------------------------------------------------------------------
+def _drop(x, keep, p):
+    """nn.Dropout in training mode given its Bernoulli keep-mask (None = identity)."""
+    if keep is None or p == 0.0:
+        return x
+    return x * keep.to(x.dtype) / (1.0 - p)
+
+
+# --------------------------------------------------------------------------------------
+# edge scorers (model.py:8-45 EdgeProbMLP, 91-133 EdgeProbGCN) and GNN (model.py:147-164)
+# --------------------------------------------------------------------------------------
+def edge_score(xs, ys, fc1_w, fc1_b, fc2_w, fc2_b, p=0.0, keep=None):
+    """`_edge_score` closures (model.py:29-34 / 115-122) on already gathered endpoint
+    codes: sigmoid(fc2(drop(relu(fc1([x*y | x-y])))))  -> [E,1]."""
+    feat = torch.cat([xs * ys, xs - ys], dim=1)
+    h = F.relu(feat @ fc1_w.t() + fc1_b)
+    h = _drop(h, keep, p)
+    return torch.sigmoid(h @ fc2_w.t() + fc2_b)
+
+
+@dataclass
+class Masks:
+    """Explicit dropout keep-masks for one forward (None everywhere = eval / p=0)."""
+    enc_hidden: Optional[torch.Tensor] = None    # [N,H]  scorer encoder, model.py:107/110
+    score_hidden: Optional[torch.Tensor] = None  # [E',H] _edge_score hidden, model.py:121
+    gnn_hidden: Optional[torch.Tensor] = None    # [N,H]  GNNModel, model.py:160
+    mlp_x: Optional[torch.Tensor] = None         # [E',H] EdgeProbMLP model.py:21/24
+    mlp_y: Optional[torch.Tensor] = None         # [E',H] EdgeProbMLP model.py:22/25
+
+
+def edge_prob_gcn(P: Dict[str, torch.Tensor], x, edge_index, rsei=None, p=0.0, masks: Masks = Masks(),
+                  return_codes: bool = False):
+    """EdgeProbGCN.forward (model.py:102-133): encoder over `rsei` (or edge_index when
+    None), scores for every column of `edge_index`."""
+    g = rsei if rsei is not None else edge_index
+    out = F.relu(gcn_conv(x, g, None, P["edge_prob_mlp.gcn1.lin.weight"], P["edge_prob_mlp.gcn1.bias"]))
+    out = _drop(out, masks.enc_hidden, p)
+    out = F.relu(gcn_conv(out, g, None, P["edge_prob_mlp.gcn2.lin.weight"], P["edge_prob_mlp.gcn2.bias"]))
+    prob = edge_score(out[edge_index[0]], out[edge_index[1]],
+                      P["edge_prob_mlp.fc1.weight"], P["edge_prob_mlp.fc1.bias"],
+                      P["edge_prob_mlp.fc2.weight"], P["edge_prob_mlp.fc2.bias"], p, masks.score_hidden)
+    return (prob, out) if return_codes else prob
+
+
+def edge_prob_mlp(P, x, edge_index, rsei=None, p=0.0, masks: Masks = Masks()):
+    """EdgeProbMLP.forward (model.py:16-45): fcdim on the gathered raw features of
+    `rsei` (or edge_index), then _edge_score on those rows."""
+    g = rsei if rsei is not None else edge_index
+    W, b = P["edge_prob_mlp.fcdim.weight"], P["edge_prob_mlp.fcdim.bias"]
+    xx = _drop(F.relu(x[g[0]] @ W.t() + b), masks.mlp_x, p)
+    yy = _drop(F.relu(x[g[1]] @ W.t() + b), masks.mlp_y, p)
+    return edge_score(xx, yy, P["edge_prob_mlp.fc1.weight"], P["edge_prob_mlp.fc1.bias"],
+                      P["edge_prob_mlp.fc2.weight"], P["edge_prob_mlp.fc2.bias"], p, masks.score_hidden)
+
+
+def gnn_forward(P, x, edge_index, edge_weight=None, p=0.0, keep=None):
+    """GNNModel.forward (model.py:155-164)."""
+    h = F.relu(gcn_conv(x, edge_index, edge_weight, P["gcn1.lin.weight"], P["gcn1.bias"]))
+    h = _drop(h, keep, p)
+    return gcn_conv(h, edge_index, edge_weight, P["gcn2.lin.weight"], P["gcn2.bias"])
+
+
+# --------------------------------------------------------------------------------------
+# gate + losses (training_hybrid.py:92-133, utils.py:163-169, 187-211)
+# --------------------------------------------------------------------------------------
+def micro_f1(logits, y, mask) -> float:
+    """utils.calculate_f1: sklearn micro-F1 of argmax on masked rows == accuracy."""
+    pred = logits[mask].argmax(dim=1)
+    return float((pred == y[mask]).sum().item()) / float(max(int(mask.sum().item()), 1))
+
+
+def correct_count(logits, y, mask) -> int:
+    pred = logits[mask].argmax(dim=1)
+    return int((pred == y[mask]).sum().item())
+
+
+def consistency_loss(edge_probs, edge_index, node_embeddings):
+    """utils.py:187-211."""
+    sim = F.cosine_similarity(node_embeddings[edge_index[0]], node_embeddings[edge_index[1]], dim=-1)
+    return F.mse_loss(edge_probs, sim)
+
+
+def reg1_loss(edge_probs_for_loss, sampled_edge_index, y, train_mask):
+    """training_hybrid.py:107-129.  Returns (loss2 or python 0, n_valid, label_sum)."""
+    src, dst = sampled_edge_index[0], sampled_edge_index[1]
+    train_edge = train_mask[src] & train_mask[dst]           # == isin(src, train_idx) & isin(dst, train_idx)
+    same = y[src] == y[dst]
+    labels = same[train_edge].to(edge_probs_for_loss.dtype)
+    probs = edge_probs_for_loss[train_edge]
+    lsum = float(labels.sum().item())
+    if lsum > 1:
+        return F.binary_cross_entropy(probs, labels), int(train_edge.sum().item()), lsum
+    return 0, int(train_edge.sum().item()), lsum
+
+
+@dataclass
+class StepConfig:
+    pipeline: str = "hybrid"            # hybrid | straight_through | two_pass
+    scorer: str = "GCN"                 # GCN | MLP
+    q: int = 0
+    conditional: bool = True
+    sparse_edge_mlp: bool = False
+    degree_bias_coef: float = 0.3
+    reg1: bool = True
+    reg2: bool = True
+    regularizer1_coef: float = 1.0
+    consist_reg_coef: float = 0.5
+    drop_rate: float = 0.0
+
+
+@dataclass
+class StepNoise:
+    prior_noise: Optional[torch.Tensor] = None     # [E] Exp(1) for the prior-only draw
+    sample_noise: Optional[torch.Tensor] = None    # [E] Exp(1) for the learned draw
+    masks_pass1: Masks = field(default_factory=Masks)
+    masks_pass3: Masks = field(default_factory=Masks)          # two_pass re-score
+    gnn_keep_learned: Optional[torch.Tensor] = None
+    gnn_keep_random: Optional[torch.Tensor] = None
+
+
+def learned_step_forward(P: Dict[str, torch.Tensor], batch, cfg: StepConfig, noise: StepNoise,
+                         force_gate: Optional[bool] = None):
+    """One `mode == 'learned'`, `E > q` step up to (and including) the loss, for the three
+    pipelines: training_hybrid.py:41-141, training_straight_through.py:38-130,
+    training_two_pass.py:38-135.  `P` maps the reference's state_dict keys to leaf tensors
+    (requires_grad as the caller wishes).  Returns a dict of every intermediate."""
+    x, ei, y, tm, prior = batch["x"], batch["edge_index"], batch["y"], batch["train_mask"], batch["prob"]
+    q, p = cfg.q, cfg.drop_rate
+    scorer = edge_prob_gcn if cfg.scorer == "GCN" else edge_prob_mlp
+    R: Dict[str, object] = {}
+
+    rsei = None
+    if cfg.conditional or cfg.sparse_edge_mlp:
+        ridx = prior_draw(prior, noise.prior_noise, q)
+        rsei = ei[:, ridx]
+        R["random_idx"] = ridx
+        R["rsei"] = rsei
+
+    if cfg.pipeline == "two_pass":
+        with torch.no_grad():
+            probs_full = scorer(P, x, ei, rsei, p, noise.masks_pass1).squeeze()
+        probs_in = probs_full
+    else:
+        probs_full = scorer(P, x, ei, rsei, p, noise.masks_pass1).squeeze()
+        probs_in = probs_full.detach() if cfg.pipeline == "hybrid" else probs_full
+    R["edge_probs_full"] = probs_full
+
+    mask, st_w = gumbel_softmax_sampling(prior, probs_in, q, cfg.degree_bias_coef, False, noise.sample_noise)
+    sei = ei[:, mask]
+    R["mask"], R["sei"] = mask, sei
+
+    if cfg.pipeline == "hybrid":
+        w = probs_full[mask]
+    elif cfg.pipeline == "straight_through":
+        w = st_w
+    else:  # two_pass: re-score the sampled edges, encoder over the learned graph
+        w = scorer(P, x, sei, None, p, noise.masks_pass3).squeeze()
+    R["w"] = w
+
+    learned_out = gnn_forward(P, x, sei, w, p, noise.gnn_keep_learned)
+    R["learned_out"] = learned_out
+
+    update_edge_mlp = True
+    random_out = None
+    if cfg.conditional:
+        random_out = gnn_forward(P, x, rsei, None, p, noise.gnn_keep_random)
+        R["random_out"] = random_out
+        lc, rc = correct_count(learned_out, y, tm), correct_count(random_out, y, tm)
+        R["learned_correct"], R["random_correct"] = lc, rc
+        update_edge_mlp = lc > rc          # f1 = correct / n_train on both sides (utils.py:163-169)
+    if force_gate is not None:
+        update_edge_mlp = force_gate
+    R["update_edge_mlp"] = update_edge_mlp
+
+    if update_edge_mlp:
+        loss = F.cross_entropy(learned_out[tm], y[tm])
+        R["ce"] = loss
+        if cfg.reg1:
+            l2, nvalid, lsum = reg1_loss(w, sei, y, tm)
+            R["reg1"], R["reg1_nvalid"], R["reg1_labelsum"] = l2, nvalid, lsum
+            loss = loss + cfg.regularizer1_coef * l2
+        if cfg.reg2:
+            l3 = consistency_loss(w, sei, learned_out)
+            R["reg2"] = l3
+            loss = loss + cfg.consist_reg_coef * l3
+    else:
+        loss = F.cross_entropy(random_out[tm], y[tm])
+        R["ce"] = loss
+    R["loss"] = loss
+    return R
+
+
+def adam_step(params, grads, state, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """torch.optim.Adam single step (no amsgrad), params updated in place."""
+    b1, b2 = betas
+    for k, prm in params.items():
+        g = grads.get(k)
+        if g is None:
+            continue
+        st = state.setdefault(k, {"t": 0, "m": torch.zeros_like(prm), "v": torch.zeros_like(prm)})
+        st["t"] += 1
+        if weight_decay:
+            g = g + weight_decay * prm
+        st["m"].mul_(b1).add_(g, alpha=1 - b1)
+        st["v"].mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** st["t"], 1 - b2 ** st["t"]
+        denom = (st["v"].sqrt() / math.sqrt(bc2)).add_(eps)
+        prm.data.addcdiv_(st["m"], denom, value=-lr / bc1)
+
+
+# --------------------------------------------------------------------------------------
+# parameter construction with the reference's state_dict keys
+# --------------------------------------------------------------------------------------
+def init_params(in_channels: int, hidden: int, num_classes: int, scorer: str = "GCN",
+                seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Random parameters under the reference's names/shapes.  Initialisers mirror PyG
+    (glorot lin, zero bias) and nn.Linear (kaiming-uniform a=sqrt(5)); biases are made
+    non-zero-free random here on purpose so parity tests exercise them."""
+    g = torch.Generator().manual_seed(seed)
+
+    def glorot(o, i):
+        a = math.sqrt(6.0 / (i + o))
+        return (torch.rand(o, i, generator=g, dtype=dtype) * 2 - 1) * a
+
+    def lin(o, i):
+        bound = 1.0 / math.sqrt(i)
+        return ((torch.rand(o, i, generator=g, dtype=dtype) * 2 - 1) * bound,
+                (torch.rand(o, generator=g, dtype=dtype) * 2 - 1) * bound)
+
+    P: Dict[str, torch.Tensor] = {}
+    if scorer == "GCN":
+        P["edge_prob_mlp.gcn1.bias"] = (torch.rand(hidden, generator=g, dtype=dtype) - 0.5) * 0.1
+        P["edge_prob_mlp.gcn1.lin.weight"] = glorot(hidden, in_channels)
+        P["edge_prob_mlp.gcn2.bias"] = (torch.rand(hidden, generator=g, dtype=dtype) - 0.5) * 0.1
+        P["edge_prob_mlp.gcn2.lin.weight"] = glorot(hidden, hidden)
+    else:
+        P["edge_prob_mlp.fcdim.weight"], P["edge_prob_mlp.fcdim.bias"] = lin(hidden, in_channels)
+    P["edge_prob_mlp.fc1.weight"], P["edge_prob_mlp.fc1.bias"] = lin(hidden, 2 * hidden)
+    P["edge_prob_mlp.fc2.weight"], P["edge_prob_mlp.fc2.bias"] = lin(1, hidden)
+    P["gcn1.bias"] = (torch.rand(hidden, generator=g, dtype=dtype) - 0.5) * 0.1
+    P["gcn1.lin.weight"] = glorot(hidden, in_channels)
+    P["gcn2.bias"] = (torch.rand(num_classes, generator=g, dtype=dtype) - 0.5) * 0.1
+    P["gcn2.lin.weight"] = glorot(num_classes, hidden)
+    return P
