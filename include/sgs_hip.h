@@ -1,0 +1,251 @@
+/*
+ * sgs_hip.h -- C ABI of libsgs_hip.so, the MI355X (gfx950) implementation of the SGS-GNN
+ * hot path: edge scoring -> exponential-race top-q edge sampling -> weighted sparse GCN
+ * forward/backward (+ gate and losses).
+ *
+ * The reference (anonymousauthors001/SGS-GNN) has no native/FFI layer: its boundary is the
+ * Python call sites of training_hybrid.py / sampling.py / model.py.  Each entry point below
+ * names the reference lines whose device work it replaces; INTEGRATION.md shows the ctypes
+ * binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked "host"; tensors are dense row-major;
+ *   - `edge_index` is PyG's int64 [2,E] layout: src = edge_index, dst = edge_index + E;
+ *   - inputs are borrowed, outputs are caller-allocated; no entry point allocates, frees,
+ *     synchronises the device or keeps global state -> all are HIP-graph capturable;
+ *   - scratch memory comes from the caller: query `*_workspace_bytes`, pass `ws, ws_bytes`;
+ *   - work is enqueued on `stream` (a hipStream_t cast to void*; NULL = default stream);
+ *   - return value: SGS_OK or a negative SGS_E* code; `sgs_last_error()` gives the
+ *     thread-local message (the reference only ever raises RuntimeError/ValueError: the
+ *     Python host layer turns a non-zero code into RuntimeError).
+ */
+#ifndef SGS_HIP_H_
+#define SGS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGS_ABI_VERSION 1
+
+#define SGS_OK 0
+#define SGS_EINVAL (-1)    /* bad argument (shape, null pointer, q > E ...) */
+#define SGS_EWORKSPACE (-2) /* workspace too small */
+#define SGS_EHIP (-3)      /* a HIP runtime call failed */
+
+typedef void* sgs_stream_t;
+
+int sgs_abi_version(void);
+const char* sgs_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Counter-based randomness (replaces torch's global generator draws).
+ *   sgs_exp_noise   : noise[e] ~ Exp(1), Philox4x32-10 keyed by `seed`, counter (e, stream_id).
+ *                     The sampler generates exactly these values in-register when it is given
+ *                     noise == NULL (reference: the exponential_() inside torch.multinomial,
+ *                     sampling.py:96, training_hybrid.py:47).
+ *   sgs_dropout_keep: keep[r*cols+c] in {0,1}, P(keep)=1-p, hash of (seed, site, r, c); the
+ *                     same bits the fused kernels apply (reference: nn.Dropout at
+ *                     model.py:107,121,160).  Only tests need the materialised form.
+ * ---------------------------------------------------------------------------------- */
+int sgs_exp_noise(uint64_t seed, uint64_t stream_id, int64_t E, float* noise, sgs_stream_t stream);
+int sgs_dropout_keep(uint64_t seed, uint32_t site, int64_t rows, int64_t cols, float p, uint8_t* keep,
+                     sgs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K0 / K2 / K3: fused exponential-race top-q edge sampler + stable compaction.
+ *
+ * Replaces, in one call:
+ *   mode SGS_SAMPLE_LEARNED  sampling.py:91-96,134-139 (`gumbel_softmax_sampling`: normalise,
+ *                            mix with the degree prior unless istest, multinomial w/o
+ *                            replacement, one-hot mask) + training_hybrid.py:83,86
+ *                            (`edge_index[:, mask]`, `edge_probs_full[mask]`);
+ *   mode SGS_SAMPLE_PRIOR    training_hybrid.py:46-48 (softmax(batch.prob), multinomial,
+ *                            column gather) -- output is in ORIGINAL edge order (the
+ *                            reference's race order is irrelevant to every consumer).
+ *
+ *   s_e   = p_e / (sum(p) + 1e-12)                      (learned)
+ *         = (1-c) * s_e + c * prior_e                   (learned, prior != NULL, i.e. !istest)
+ *         = exp(p_e - max p) / sum exp(p - max p)       (prior mode: softmax of `p`)
+ *   key_e = s_e / noise_e        IEEE fp32 divide, noise ~ Exp(1)
+ *   selected = the q largest keys; ties broken towards the LOWEST edge id.
+ *
+ * `noise` may be NULL: then noise_e is generated in-register exactly as sgs_exp_noise(seed,
+ * stream_id) would.  Outputs (any may be NULL except mask): mask[E] (0/1 bytes, torch.bool
+ * compatible), sampled_eid[q] ascending edge ids, sampled_edge_index[2,q], sampled_p[q] =
+ * p[sampled_eid], stats[4] = {Z (sum p or sum exp), max (prior mode), threshold key, #ties
+ * taken at the threshold}.  keys_out[E] (optional) receives the fp32 keys (tests only).
+ * ---------------------------------------------------------------------------------- */
+#define SGS_SAMPLE_LEARNED 0
+#define SGS_SAMPLE_PRIOR 1
+
+size_t sgs_sample_topq_workspace_bytes(int64_t E);
+int sgs_sample_topq(int mode, const float* p, const float* prior, double degree_bias_coef,
+                    const float* noise, uint64_t seed, uint64_t stream_id, int64_t E, int64_t q,
+                    const int64_t* edge_index, uint8_t* mask, int64_t* sampled_eid,
+                    int64_t* sampled_edge_index, float* sampled_p, float* stats, float* keys_out,
+                    void* ws, size_t ws_bytes, sgs_stream_t stream);
+
+/* Straight-through weights of sampling.py:137-138,155 for the selected edges:
+ *   w_j = clamp(p_e * ((1 - s_e) + s_e), 0, 1),  e = sampled_eid[j]   (forward value)
+ * and its exact autograd backward wrt p (s depends on every p through sum(p)):
+ *   dp_e += [e selected] g_e ((1 - s_e) + s_e) + ... (see DESIGN.md "straight-through").
+ * Used by --pipeline straight_through and by evaluate.py.  prior == NULL <=> istest. */
+int sgs_st_weights_fwd(const float* p, const float* prior, double degree_bias_coef, const float* stats,
+                       const int64_t* sampled_eid, int64_t E, int64_t q, float* w, sgs_stream_t stream);
+size_t sgs_st_weights_bwd_workspace_bytes(int64_t E, int64_t q);
+int sgs_st_weights_bwd(const float* p, const float* prior, double degree_bias_coef, const float* stats,
+                       const int64_t* sampled_eid, const float* grad_w, int64_t E, int64_t q, float* grad_p,
+                       void* ws, size_t ws_bytes, sgs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K4: graph preparation for the GCN layers = the bookkeeping half of PyG's
+ * add_remaining_self_loops + gcn_norm, done ONCE per sampled graph and shared by both layers,
+ * forward and backward (the reference redoes it inside every GCNConv call: model.py:107-111,
+ * 159-161).
+ *
+ * For the n_edges edges (src,dst) of `edge_index` [2,n_edges] over N nodes, builds both CSR
+ * orientations, rows ordered by edge id (deterministic, so every floating-point row sum is
+ * run-to-run reproducible):
+ *   in_ptr[N+1],  in_src[n_edges],  in_eid[n_edges]    rows = dst   (forward aggregation)
+ *   out_ptr[N+1], out_dst[n_edges], out_eid[n_edges]   rows = src   (transposed / backward)
+ *   loop_eid[N] = id of the LAST existing self-loop edge of node i, or -1  (PyG: an existing
+ *                 loop keeps its weight, otherwise the added loop has weight 1)
+ * Self-loop edges stay in the CSRs (the edge scorer's backward needs them); the norm kernel
+ * gives them weight 0 there and routes them through the loop term.  int32 indices.
+ * ---------------------------------------------------------------------------------- */
+size_t sgs_graph_build_workspace_bytes(int64_t n_edges, int64_t N);
+int sgs_graph_build(const int64_t* edge_index, int64_t n_edges, int64_t N, int32_t* in_ptr, int32_t* in_src,
+                    int32_t* in_eid, int32_t* out_ptr, int32_t* out_dst, int32_t* out_eid, int32_t* loop_eid,
+                    void* ws, size_t ws_bytes, sgs_stream_t stream);
+
+/* gcn_norm forward (PyG gcn_norm, add_self_loops=True, flow source_to_target):
+ *   loopw_i = w[loop_eid_i] or 1;  deg_i = loopw_i + sum_{e=(j->i), j!=i} w_e;  dis = deg^-1/2 (inf -> 0)
+ *   what_in[k]  = dis[src] * w * dis[dst] in dst-CSR order,  what_out[k] the same in src-CSR order
+ *   what_loop[i] = dis_i * loopw_i * dis_i
+ * w == NULL means unit weights. */
+int sgs_gcn_norm_fwd(const float* w, int64_t n_edges, int64_t N, const int32_t* in_ptr, const int32_t* in_src,
+                     const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
+                     const int32_t* loop_eid, float* dis, float* loopw, float* what_in, float* what_out,
+                     float* what_loop, sgs_stream_t stream);
+
+/* gcn_norm backward: from gw_hat[e] = dL/d(what_e) (edge-id order) and gloop[i] = dL/d(what_loop_i)
+ * to dL/dw_e, through both the message weight and the degree normalisation:
+ *   dw_e = gw_hat_e dis_s dis_t + Hn_t,            Hn_t = -1/2 dis_t^3 G_t
+ *   G_t  = sum_{e' into t} gw_hat_e' w_e' dis_src + sum_{e' out of t} gw_hat_e' w_e' dis_dst
+ *          + 2 gloop_t loopw_t dis_t
+ * (every existing self-loop edge (i,i) gets gloop_i dis_i^2 + Hn_i -- also a duplicate whose weight was
+ * overwritten, which is what autograd does for PyG's `loop_attr[idx] = edge_attr[inv_mask]`). */
+size_t sgs_gcn_norm_bwd_workspace_bytes(int64_t N);
+int sgs_gcn_norm_bwd(const float* w, const float* gw_hat, const float* gloop, int64_t n_edges, int64_t N,
+                     const float* dis, const float* loopw, const int32_t* in_ptr, const int32_t* in_src,
+                     const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
+                     const int32_t* loop_eid, const int64_t* edge_index, float* dw, void* ws, size_t ws_bytes,
+                     sgs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K5: weighted CSR SpMM with fused epilogue (GCNConv propagate + bias, F.relu, nn.Dropout;
+ * model.py:107-111,159-161):
+ *   Y[i,:] = act( sum_{k in row i} val[k] X[col[k],:] + diag[i] X[i,:] + bias )
+ * act: identity | ReLU | ReLU then counter-based dropout(p, seed, site) (see sgs_dropout_keep).
+ * Forward uses (in_ptr, in_src, what_in, what_loop); the transposed product of backward,
+ * dX = A_hat^T dZ, is the same call with (out_ptr, out_dst, what_out, what_loop).
+ * diag / bias may be NULL.  X is the already linearly transformed feature matrix [N,D]
+ * (the dense X W^T is a library GEMM on the host side).
+ * ---------------------------------------------------------------------------------- */
+#define SGS_ACT_NONE 0
+#define SGS_ACT_RELU 1
+#define SGS_ACT_RELU_DROPOUT 2
+int sgs_spmm_csr(const float* X, int64_t N, int64_t D, const int32_t* ptr, const int32_t* col, const float* val,
+                 const float* diag, const float* bias, int act, float p_drop, uint64_t seed, uint32_t site, float* Y,
+                 sgs_stream_t stream);
+
+/* SDDMM over the same CSR (gradient wrt the normalised weights):
+ *   g[eid[k]] = <A[i,:], B[col[k],:]> for k in row i;  gdiag[i] = <A[i,:], B[i,:]>  (gdiag may be NULL) */
+int sgs_sddmm_csr(const float* A, const float* B, int64_t N, int64_t D, const int32_t* ptr, const int32_t* col,
+                  const int32_t* eid, float* g, float* gdiag, sgs_stream_t stream);
+
+/* dZ = dY * act'(Y) for the fused epilogue above (Y is the layer OUTPUT: Y > 0 iff kept and
+ * positive, so no mask is stored);  colsum: out[d] = sum_i A[i,d]  (bias gradient). */
+int sgs_act_bwd(const float* dY, const float* Y, int64_t n, int act, float p_drop, float* dZ, sgs_stream_t stream);
+int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, sgs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K1b: fused edge scorer (model.py:29-34 / 115-122 `_edge_score`; never materialises the
+ * reference's [E,2H] feature or [E,H] hidden tensors):
+ *   p_e = sigmoid( w2 . drop(relu( W1 [x_s*x_d | x_s-x_d] + b1 )) + b2 ),  x = codes rows
+ * Algebraic split  W1 [x*y | x-y] = W1a (x*y) + U[s] - U[d]  with U = codes W1b^T a node-level
+ * library GEMM done by the caller, so the per-edge contraction is H x H; it runs on the f32
+ * matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
+ *   codes, U [N,H] f32; W1 = fc1.weight [H,2H]; b1 [H]; w2 = fc2.weight [H]; b2 [1].
+ *   4 <= H <= 256, H % 4 == 0.  Dropout on the hidden layer is counter-based, row = edge id.
+ * ws: sgs_edge_score_workspace_bytes(H).
+ *
+ * sgs_edge_score_bwd_core runs over an explicit list of active edges (hybrid / two-pass: the q
+ * sampled edges -- every other edge has exactly zero upstream gradient; NULL = all E edges in
+ * order) and RECOMPUTES the hidden layer instead of storing it.  It writes, per active row j:
+ *   dv[j,:]  = dL/d(fc1 pre-activation)       hdz[j,:] = dz_j * hidden_j   (colsum -> d w2)
+ *   dz[j]    = grad_p_j p_j (1-p_j)  (sum -> d b2)          feat[j,:] = x_s * x_d
+ * from which the host forms  d W1a = dv^T feat,  d b1 = colsum(dv),  dfeat = dv W1a  (library
+ * GEMMs) and the two endpoint reductions below.
+ *
+ * sgs_endpoint_reduce: out[v,:] = sum_{k in out-row v} sign_out M_out[out_eid[k],:] (* T[out_dst[k],:])
+ *                               + sum_{k in in-row v}  sign_in  M_in[in_eid[k],:]   (* T[in_src[k],:])
+ * over the CSRs of the ACTIVE edge list (sgs_graph_build): the scatter of per-edge gradient rows
+ * to both endpoints as a deterministic gather (no float atomics).  T may be NULL.
+ *   d codes (direct) = reduce(dfeat, dfeat, T = codes, +1, +1);   d U = reduce(dv, dv, NULL, +1, -1).
+ * ---------------------------------------------------------------------------------- */
+size_t sgs_edge_score_workspace_bytes(int64_t H);
+int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
+                       const float* W1, const float* b1, const float* w2, const float* b2, float p_drop,
+                       uint64_t seed, uint32_t site, float* p_out, void* ws, size_t ws_bytes, sgs_stream_t stream);
+int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index,
+                            int64_t E, const int64_t* active_eid, int64_t n_active, const float* grad_p,
+                            const float* W1, const float* b1, const float* w2, const float* b2, float p_drop,
+                            uint64_t seed, uint32_t site, float* dv, float* hdz, float* dz, float* feat, void* ws,
+                            size_t ws_bytes, sgs_stream_t stream);
+int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, int64_t N, int64_t H,
+                        const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid, const int32_t* out_ptr,
+                        const int32_t* out_dst, const int32_t* out_eid, float sign_out, float sign_in, float* out,
+                        sgs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K6: gate and losses (training_hybrid.py:92-133, utils.py:163-169, 187-211), all on device.
+ * ---------------------------------------------------------------------------------- */
+/* correct[0] = #{i in train : argmax_c logits[i,c] == y_i} (first maximum wins), correct[1] = #train.
+ * micro-F1 of utils.calculate_f1 == correct[0] / correct[1]; the gate compares two such counts. */
+int sgs_masked_correct(const float* logits, int64_t N, int64_t C, const int64_t* y, const uint8_t* train_mask,
+                       int32_t* correct, sgs_stream_t stream);
+
+/* criterion(out[train_mask], y[train_mask]) for criterion = nn.CrossEntropyLoss() (main.py:125;
+ * training_hybrid.py:105,139,145): loss[0] = mean over train rows of (logsumexp - logit[y]).
+ * row_lse[N], rowloss[N], n_rows[1] are caller scratch kept for backward:
+ * dlogits[i,c] = (softmax - onehot) * grad_loss / #train on train rows, 0 elsewhere. */
+int sgs_masked_ce_fwd(const float* logits, int64_t N, int64_t C, const int64_t* y, const uint8_t* train_mask,
+                      float* loss, float* row_lse, float* rowloss, int32_t* n_rows, sgs_stream_t stream);
+int sgs_masked_ce_bwd(const float* logits, int64_t N, int64_t C, const int64_t* y, const uint8_t* train_mask,
+                      const float* row_lse, const int32_t* n_rows, const float* grad_loss, float* dlogits,
+                      sgs_stream_t stream);
+
+/* The two edge regularisers on the q sampled edges (weights w, endpoints sampled_edge_index [2,q]):
+ *   reg1 = BCE(w[valid], [y_s == y_d]), valid = both endpoints are train nodes; 0 unless the labels sum
+ *          to more than 1 (training_hybrid.py:107-129; the reference's torch.isin + .item() sync)
+ *   reg2 = mean_j (w_j - cos(logits[s_j], logits[d_j]))^2           (utils.consistency_loss)
+ * out[5] = {reg1, reg2, #valid, sum labels, coef1*reg1 + coef2*reg2}.
+ * Backward: dw[q] and per-edge gradient rows Gs, Gd [q,C] wrt logits[src], logits[dst]; the caller
+ * folds them into dlogits with sgs_endpoint_reduce(Gs, Gd, NULL, +1, +1) over the sampled graph. */
+size_t sgs_edge_reg_workspace_bytes(int64_t q);
+int sgs_edge_reg_fwd(const float* w, const int64_t* sampled_edge_index, int64_t q, const float* logits, int64_t N,
+                     int64_t C, const int64_t* y, const uint8_t* train_mask, float coef1, float coef2, float* out,
+                     float* cos_out, void* ws, size_t ws_bytes, sgs_stream_t stream);
+int sgs_edge_reg_bwd(const float* w, const int64_t* sampled_edge_index, int64_t q, const float* logits, int64_t N,
+                     int64_t C, const int64_t* y, const uint8_t* train_mask, const float* out, float coef1,
+                     float coef2, const float* grad_loss, float* dw, float* Gs, float* Gd, sgs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGS_HIP_H_ */

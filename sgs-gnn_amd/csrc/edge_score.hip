@@ -1,0 +1,359 @@
+// K1b: fused edge scorer on the f32 matrix cores (gfx950, v_mfma_f32_32x32x2_f32 = exact fp32).
+//
+// Reference: the `_edge_score` closures, model.py:29-34 / 115-122:
+//     p_e = sigmoid( fc2( dropout( relu( fc1( [x_s * x_d | x_s - x_d] ) ) ) ) )
+// which materialise [E,2H] features and [E,H] hidden activations (>= 10 KB per edge).  Here a
+// workgroup owns a tile of 128 edges and all H hidden units and nothing per-edge but p_e (4 B)
+// is written.  Algebraic split:
+//     W1 [x*y | x-y] = W1a (x*y) + U[s] - U[d],   U = codes W1b^T  (node-level GEMM, host side)
+// so the per-edge contraction is H x H instead of H x 2H.
+//
+// MFMA mapping: D[h][e] = sum_k W1a[h][k] * (x_s[k] x_d[k]):  A = W1a (rows h -> accumulator
+// registers), B = the gathered Hadamard features (cols e -> lanes).  With the hidden units in
+// registers the fc2 reduction over h is in-lane plus one cross-half shuffle.  Per 32-deep
+// k-step a workgroup stages W1a^T[k0:k0+32][0:H] (coalesced, k-major) and the 128x32 feature
+// tile ([k][e] image, conflict-free ds_read_b32 for the B operand) in LDS.
+// Roofline: MFMA-bound (4 H^2 / 2 flops per edge after the split vs ~4 KB of L2 traffic).
+#include "sgs_common.h"
+
+namespace sgs {
+namespace {
+
+constexpr int kT = 256;      // 4 waves
+constexpr int kBM = 128;     // edges per workgroup (32 per wave)
+constexpr int kBK = 32;      // k-step
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// W1 [H][2H] (fc1.weight) -> WaT [k][h] = W1[h][k], k < H
+__global__ void __launch_bounds__(kT) transpose_w1a(const float* __restrict__ W1, int H, float* __restrict__ WaT) {
+    __shared__ float t[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;   // bx: k block, by: h block
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int h = by + r, k = bx + tx;
+        t[r][tx] = (h < H && k < H) ? W1[static_cast<int64_t>(h) * 2 * H + k] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int k = bx + r, h = by + tx;
+        if (k < H && h < H) WaT[static_cast<int64_t>(k) * H + h] = t[tx][r];
+    }
+}
+
+struct ScoreArgs {
+    const float* codes;      // [N,H]
+    const float* U;          // [N,H] = codes W1b^T
+    const int64_t* src;      // [E]
+    const int64_t* dst;      // [E]
+    const int64_t* active;   // [n] edge ids (backward) or nullptr = identity
+    int64_t n;               // rows processed (E forward, n_active backward)
+    int H;
+    const float* WaT;        // [H][H] k-major
+    const float* b1;
+    const float* w2;
+    const float* b2;
+    float drop_scale;
+    uint32_t drop_thresh;
+    uint64_t seed;
+    uint32_t site;
+    int use_drop;
+    float* p_out;            // forward: [n]
+    const float* gp;         // backward: [n]
+    float* dv;               // backward: [n,H]  dL/d(pre-activation)
+    float* hdz;              // backward: [n,H]  dz * dropped hidden  (column-sums to dw2)
+    float* dz;               // backward: [n]
+    float* feat;             // backward: [n,H]  x_s * x_d
+};
+
+template <int NT, bool BWD>
+__global__ void __launch_bounds__(kT, 2) edge_score_kernel(ScoreArgs a) {
+    constexpr int HP = 32 * NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Wt_s = reinterpret_cast<float*>(smem);                 // [32][HP]
+    float* Ft_s = Wt_s + kBK * HP;                                // [32][128]
+    int* s_idx = reinterpret_cast<int*>(Ft_s + kBK * kBM);        // [128]
+    int* d_idx = s_idx + kBM;                                     // [128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = a.H;
+    const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kBM;
+
+    if (tid < kBM) {
+        const int64_t r = row0 + tid;
+        int s = 0, d = 0;
+        if (r < a.n) {
+            const int64_t e = a.active ? a.active[r] : r;
+            s = static_cast<int>(a.src[e]);
+            d = static_cast<int>(a.dst[e]);
+        }
+        s_idx[tid] = s;
+        d_idx[tid] = d;
+    }
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int kh = lane >> 5, l31 = lane & 31;
+    for (int k0 = 0; k0 < H; k0 += kBK) {
+        __syncthreads();   // previous tile fully consumed (also publishes s_idx/d_idx on the first trip)
+        // ---- stage W1a^T[k0:k0+32][0:HP] (zero padded)
+        for (int i = tid; i < kBK * (HP / 4); i += kT) {
+            const int k = i / (HP / 4), h4 = (i % (HP / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 + k < H && h4 < H) v = *reinterpret_cast<const float4*>(a.WaT + static_cast<int64_t>(k0 + k) * H + h4);
+            *reinterpret_cast<float4*>(Wt_s + k * HP + h4) = v;
+        }
+        // ---- stage the Hadamard feature tile as [k][e]
+#pragma unroll
+        for (int it = 0; it < (kBM * (kBK / 4)) / kT; ++it) {
+            const int id = it * kT + tid;
+            const int e = id & (kBM - 1), c = id >> 7;          // c: float4 chunk 0..7 of the k-step
+            const int kk = k0 + 4 * c;
+            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kk < H) {
+                const float4 x = *reinterpret_cast<const float4*>(a.codes + static_cast<int64_t>(s_idx[e]) * H + kk);
+                const float4 y = *reinterpret_cast<const float4*>(a.codes + static_cast<int64_t>(d_idx[e]) * H + kk);
+                f = make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
+                if (BWD) {
+                    const int64_t r = row0 + e;
+                    if (r < a.n) *reinterpret_cast<float4*>(a.feat + r * H + kk) = f;
+                }
+            }
+            Ft_s[(4 * c + 0) * kBM + e] = f.x;
+            Ft_s[(4 * c + 1) * kBM + e] = f.y;
+            Ft_s[(4 * c + 2) * kBM + e] = f.z;
+            Ft_s[(4 * c + 3) * kBM + e] = f.w;
+        }
+        __syncthreads();
+        // ---- 16 x NT MFMAs: A = W1a (row h), B = features (col e)
+#pragma unroll
+        for (int kk = 0; kk < kBK; kk += 2) {
+            const float b = Ft_s[(kk + kh) * kBM + 32 * wave + l31];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float av = Wt_s[(kk + kh) * HP + 32 * t + l31];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: lane = edge (l31) x half (kh); acc[t][r] is hidden unit 32t + (r&3) + 8(r>>2) + 4kh
+    const int el = 32 * wave + l31;
+    const int64_t r = row0 + el;
+    const bool live = r < a.n;
+    const int64_t eg = live ? (a.active ? a.active[r] : r) : 0;   // global edge id: dropout row
+    const float* Us = a.U + static_cast<int64_t>(s_idx[el]) * H;
+    const float* Ud = a.U + static_cast<int64_t>(d_idx[el]) * H;
+    float z = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int hb = 32 * t + 8 * g + 4 * kh;
+            if (hb < H) {
+                const float4 us = *reinterpret_cast<const float4*>(Us + hb);
+                const float4 ud = *reinterpret_cast<const float4*>(Ud + hb);
+                const float4 bb = *reinterpret_cast<const float4*>(a.b1 + hb);
+                const float4 ww = *reinterpret_cast<const float4*>(a.w2 + hb);
+                const float u4[4] = {us.x - ud.x, us.y - ud.y, us.z - ud.z, us.w - ud.w};
+                const float b4[4] = {bb.x, bb.y, bb.z, bb.w};
+                const float w4[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = (acc[t][4 * g + j] + u4[j]) + b4[j];
+                    float m = v > 0.f ? 1.f : 0.f;                 // relu'
+                    if (a.use_drop)
+                        m = dropout_keep_at(a.seed, a.site, static_cast<uint64_t>(eg), static_cast<uint32_t>(hb + j), a.drop_thresh)
+                                ? m * a.drop_scale : 0.f;
+                    const float hd = v * m;                          // dropout(relu(v))
+                    z = fmaf(w4[j], hd, z);
+                    if (BWD) { acc[t][4 * g + j] = hd; }             // keep for the second epilogue pass
+                    (void)m;
+                }
+            }
+        }
+    }
+    z += __shfl_xor(z, 32, 64);
+    z += a.b2[0];
+    const float p = 1.0f / (1.0f + expf(-z));
+    if (!BWD) {
+        if (live && kh == 0) a.p_out[r] = p;
+        return;
+    }
+    // ---- backward epilogue: dz = gp p (1-p);  dv = dz w2 relu' keep scale;  hdz = dz hd
+    const float dzv = live ? a.gp[r] * p * (1.0f - p) : 0.f;
+    if (live && kh == 0) a.dz[r] = dzv;
+    if (!live) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int hb = 32 * t + 8 * g + 4 * kh;
+            if (hb < H) {
+                const float4 ww = *reinterpret_cast<const float4*>(a.w2 + hb);
+                const float w4[4] = {ww.x, ww.y, ww.z, ww.w};
+                float dv4[4], hz4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float hd = acc[t][4 * g + j];
+                    // hd > 0  <=>  v > 0 and kept; then d hd / d v = scale (or 1 without dropout)
+                    const float m = hd > 0.f ? (a.use_drop ? a.drop_scale : 1.f) : 0.f;
+                    dv4[j] = dzv * w4[j] * m;
+                    hz4[j] = dzv * hd;
+                }
+                *reinterpret_cast<float4*>(a.dv + r * H + hb) = make_float4(dv4[0], dv4[1], dv4[2], dv4[3]);
+                *reinterpret_cast<float4*>(a.hdz + r * H + hb) = make_float4(hz4[0], hz4[1], hz4[2], hz4[3]);
+            }
+        }
+    }
+}
+
+// out[v,:] = sum_{k in out-row v} sgn_out * Mo[out_eid[k],:] (* T[out_dst[k],:])
+//          + sum_{k in in-row v}  sgn_in  * Mi[in_eid[k],:]  (* T[in_src[k],:])
+// Scatter of per-edge gradient rows to both endpoints as a deterministic gather over the two
+// CSR orientations of the active edge list (no float atomics).
+template <int VEC, bool HAS_T>
+__global__ void __launch_bounds__(kT) endpoint_reduce(const float* __restrict__ Mo, const float* __restrict__ Mi,
+                                                     const float* __restrict__ T, int64_t N, int64_t H,
+                                                     const int* __restrict__ in_ptr, const int* __restrict__ in_src,
+                                                     const int* __restrict__ in_eid, const int* __restrict__ out_ptr,
+                                                     const int* __restrict__ out_dst, const int* __restrict__ out_eid,
+                                                     float sgn_out, float sgn_in, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t v = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;   // one wave per node
+    if (v >= N) return;
+    for (int64_t c0 = static_cast<int64_t>(lane) * VEC; c0 < H; c0 += 64 * VEC) {
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+        for (int dir = 0; dir < 2; ++dir) {
+            const int* ptr = dir == 0 ? out_ptr : in_ptr;
+            const int* col = dir == 0 ? out_dst : in_src;
+            const int* eid = dir == 0 ? out_eid : in_eid;
+            const float sg = dir == 0 ? sgn_out : sgn_in;
+            const float* M = dir == 0 ? Mo : Mi;
+            const int b = ptr[v], e = ptr[v + 1];
+            for (int k = b; k < e; ++k) {
+                float m[VEC], t[VEC];
+                if (VEC == 4) {
+                    *reinterpret_cast<float4*>(m) = *reinterpret_cast<const float4*>(M + static_cast<int64_t>(eid[k]) * H + c0);
+                    if (HAS_T) *reinterpret_cast<float4*>(t) = *reinterpret_cast<const float4*>(T + static_cast<int64_t>(col[k]) * H + c0);
+                } else {
+                    m[0] = M[static_cast<int64_t>(eid[k]) * H + c0];
+                    if (HAS_T) t[0] = T[static_cast<int64_t>(col[k]) * H + c0];
+                }
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] = fmaf(sg * m[j], HAS_T ? t[j] : 1.0f, acc[j]);
+            }
+        }
+        if (VEC == 4) *reinterpret_cast<float4*>(out + v * H + c0) = *reinterpret_cast<float4*>(acc);
+        else out[v * H + c0] = acc[0];
+    }
+}
+
+inline size_t score_smem_bytes(int NT) { return static_cast<size_t>(kBK) * 32 * NT * 4 + kBK * kBM * 4 + 2 * kBM * 4; }
+
+template <bool BWD>
+int launch_score(const ScoreArgs& a, hipStream_t stream) {
+    const int H = a.H;
+    const int NT = H <= 32 ? 1 : H <= 64 ? 2 : H <= 128 ? 4 : 8;
+    const dim3 grid(static_cast<unsigned>(cdiv(a.n, kBM))), blk(kT);
+    const size_t sm = score_smem_bytes(NT);
+    switch (NT) {
+        case 1: hipLaunchKernelGGL((edge_score_kernel<1, BWD>), grid, blk, sm, stream, a); break;
+        case 2: hipLaunchKernelGGL((edge_score_kernel<2, BWD>), grid, blk, sm, stream, a); break;
+        case 4: hipLaunchKernelGGL((edge_score_kernel<4, BWD>), grid, blk, sm, stream, a); break;
+        default: hipLaunchKernelGGL((edge_score_kernel<8, BWD>), grid, blk, sm, stream, a); break;
+    }
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+inline int check_common(const char* who, int64_t N, int64_t H, int64_t E, float p_drop) {
+    SGS_REQUIRE(N >= 0 && E >= 0 && N < (int64_t(1) << 31), SGS_EINVAL, "%s: bad sizes", who);
+    SGS_REQUIRE(H >= 4 && H <= 256 && H % 4 == 0, SGS_EINVAL, "%s: hidden size H=%lld unsupported (need 4 <= H <= 256, H %% 4 == 0)",
+                who, (long long)H);
+    SGS_REQUIRE(p_drop >= 0.f && p_drop < 1.f, SGS_EINVAL, "%s: bad dropout probability", who);
+    return SGS_OK;
+}
+
+}  // namespace
+}  // namespace sgs
+
+using namespace sgs;
+
+extern "C" {
+
+size_t sgs_edge_score_workspace_bytes(int64_t H) { return carve_bytes(static_cast<size_t>(H < 0 ? 0 : H) * H, 4) + 256; }
+
+int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
+                       const float* W1, const float* b1, const float* w2, const float* b2, float p_drop, uint64_t seed,
+                       uint32_t site, float* p_out, void* ws, size_t ws_bytes, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (int rc = check_common("sgs_edge_score_fwd", N, H, E, p_drop)) return rc;
+    if (E == 0) return SGS_OK;
+    SGS_REQUIRE(codes && U && edge_index && W1 && b1 && w2 && b2 && p_out, SGS_EINVAL, "sgs_edge_score_fwd: null pointer");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_workspace_bytes(H), SGS_EWORKSPACE, "sgs_edge_score_fwd: workspace too small");
+    Carver cv(ws);
+    float* WaT = cv.take<float>(static_cast<size_t>(H) * H);
+    hipLaunchKernelGGL(transpose_w1a, dim3(cdiv(H, 32), cdiv(H, 32)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);
+    ScoreArgs a{};
+    a.codes = codes; a.U = U; a.src = edge_index; a.dst = edge_index + E; a.active = nullptr; a.n = E; a.H = static_cast<int>(H);
+    a.WaT = WaT; a.b1 = b1; a.w2 = w2; a.b2 = b2;
+    a.drop_scale = 1.0f / (1.0f - p_drop); a.drop_thresh = dropout_thresh(p_drop); a.seed = seed; a.site = site;
+    a.use_drop = p_drop > 0.f; a.p_out = p_out;
+    return launch_score<false>(a, stream);
+}
+
+/* Backward core over the active rows: recomputes the hidden layer and writes
+ * dv [n,H] = dL/d(fc1 pre-activation), hdz [n,H] = dz * hidden, dz [n], feat [n,H] = x_s*x_d. */
+int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
+                            const int64_t* active_eid, int64_t n_active, const float* grad_p, const float* W1,
+                            const float* b1, const float* w2, const float* b2, float p_drop, uint64_t seed, uint32_t site,
+                            float* dv, float* hdz, float* dz, float* feat, void* ws, size_t ws_bytes,
+                            sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (int rc = check_common("sgs_edge_score_bwd_core", N, H, E, p_drop)) return rc;
+    SGS_REQUIRE(n_active >= 0 && (active_eid || n_active == E), SGS_EINVAL,
+                "sgs_edge_score_bwd_core: n_active must equal E when active_eid is NULL");
+    if (n_active == 0) return SGS_OK;
+    SGS_REQUIRE(codes && U && edge_index && grad_p && W1 && b1 && w2 && b2 && dv && hdz && dz && feat, SGS_EINVAL,
+                "sgs_edge_score_bwd_core: null pointer");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_workspace_bytes(H), SGS_EWORKSPACE, "sgs_edge_score_bwd_core: workspace too small");
+    Carver cv(ws);
+    float* WaT = cv.take<float>(static_cast<size_t>(H) * H);
+    hipLaunchKernelGGL(transpose_w1a, dim3(cdiv(H, 32), cdiv(H, 32)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);
+    ScoreArgs a{};
+    a.codes = codes; a.U = U; a.src = edge_index; a.dst = edge_index + E; a.active = active_eid; a.n = n_active;
+    a.H = static_cast<int>(H); a.WaT = WaT; a.b1 = b1; a.w2 = w2; a.b2 = b2;
+    a.drop_scale = 1.0f / (1.0f - p_drop); a.drop_thresh = dropout_thresh(p_drop); a.seed = seed; a.site = site;
+    a.use_drop = p_drop > 0.f; a.gp = grad_p; a.dv = dv; a.hdz = hdz; a.dz = dz; a.feat = feat;
+    return launch_score<true>(a, stream);
+}
+
+int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, int64_t N, int64_t H, const int32_t* in_ptr,
+                        const int32_t* in_src,
+                        const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
+                        float sign_out, float sign_in, float* out, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && H >= 0, SGS_EINVAL, "sgs_endpoint_reduce: bad sizes");
+    if (N == 0 || H == 0) return SGS_OK;
+    SGS_REQUIRE(M_out && M_in && in_ptr && out_ptr && out, SGS_EINVAL, "sgs_endpoint_reduce: null pointer");
+    const bool v4 = H % 4 == 0 && (reinterpret_cast<uintptr_t>(M_out) & 15) == 0 && (reinterpret_cast<uintptr_t>(M_in) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                    (!T || (reinterpret_cast<uintptr_t>(T) & 15) == 0);
+    const dim3 grid(static_cast<unsigned>(cdiv(N * 64, kT))), blk(kT);
+    if (v4) {
+        if (T) hipLaunchKernelGGL((endpoint_reduce<4, true>), grid, blk, 0, stream, M_out, M_in, T, N, H, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, sign_out, sign_in, out);
+        else   hipLaunchKernelGGL((endpoint_reduce<4, false>), grid, blk, 0, stream, M_out, M_in, T, N, H, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, sign_out, sign_in, out);
+    } else {
+        if (T) hipLaunchKernelGGL((endpoint_reduce<1, true>), grid, blk, 0, stream, M_out, M_in, T, N, H, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, sign_out, sign_in, out);
+        else   hipLaunchKernelGGL((endpoint_reduce<1, false>), grid, blk, 0, stream, M_out, M_in, T, N, H, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, sign_out, sign_in, out);
+    }
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+}  // extern "C"

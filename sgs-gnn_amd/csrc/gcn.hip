@@ -1,0 +1,551 @@
+// K4 / K5: graph preparation, gcn_norm and weighted CSR SpMM / SDDMM for the GCN layers (gfx950).
+//
+// Reference: PyG 2.3.1 GCNConv as called at model.py:94-95,107-111 (scorer encoder) and
+// model.py:151-153,159-161 (GNNModel): add_remaining_self_loops -> deg = scatter_add(w, dst)
+// -> w_hat = deg^-1/2[src] w deg^-1/2[dst] -> out[dst] += w_hat x'[src] -> + bias.
+// The reference materialises [nnz, D] messages and scatter-adds them (atomics on GPU); here
+// the aggregation is a gather over a dst-sorted CSR (no float atomics, deterministic), and
+// the transposed pass of backward is the same kernel over the src-sorted CSR.
+//
+// All kernels are HBM/L2-bandwidth bound gathers: per nnz 4 B col + 4 B weight + 4*D B row.
+#include "sgs_common.h"
+
+namespace sgs {
+namespace {
+
+constexpr int kT = 256;
+constexpr int kMaxLdsRow = 8192;   // longest row sorted in LDS (32 KiB)
+
+// ---------------------------------------------------------------- CSR build
+__global__ void __launch_bounds__(kT) count_degrees(const int64_t* __restrict__ ei, int64_t n_edges, int* __restrict__ cnt_in,
+                                                   int* __restrict__ cnt_out, int* __restrict__ loop_eid) {
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (e >= n_edges) return;
+    const int s = static_cast<int>(ei[e]), d = static_cast<int>(ei[n_edges + e]);
+    atomicAdd(&cnt_in[d], 1);
+    atomicAdd(&cnt_out[s], 1);
+    if (s == d) atomicMax(&loop_eid[s], static_cast<int>(e));   // PyG: the last existing loop wins
+}
+
+// blockIdx.x = 0: in-direction, 1: out-direction.  Exclusive scan of N counts -> ptr[N+1]; also
+// initialises the fill cursors.
+__global__ void __launch_bounds__(1024) scan_counts(const int* __restrict__ cnt_in, const int* __restrict__ cnt_out,
+                                                   int64_t N, int* __restrict__ in_ptr, int* __restrict__ out_ptr,
+                                                   int* __restrict__ cur_in, int* __restrict__ cur_out) {
+    __shared__ int sums[1024];
+    const int* cnt = blockIdx.x == 0 ? cnt_in : cnt_out;
+    int* ptr = blockIdx.x == 0 ? in_ptr : out_ptr;
+    int* cur = blockIdx.x == 0 ? cur_in : cur_out;
+    const int64_t per = (N + 1023) / 1024;
+    const int64_t lo = static_cast<int64_t>(threadIdx.x) * per;
+    const int64_t hi = (lo + per < N) ? lo + per : N;
+    int s = 0;
+    for (int64_t i = lo; i < hi; ++i) s += cnt[i];
+    sums[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = (threadIdx.x >= off) ? sums[threadIdx.x - off] : 0;
+        __syncthreads();
+        sums[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = sums[threadIdx.x] - s;
+    for (int64_t i = lo; i < hi; ++i) {
+        ptr[i] = run;
+        cur[i] = run;
+        run += cnt[i];
+    }
+    if (threadIdx.x == 1023) ptr[N] = sums[1023];
+}
+
+__global__ void __launch_bounds__(kT) fill_rows(const int64_t* __restrict__ ei, int64_t n_edges, int* __restrict__ cur_in,
+                                               int* __restrict__ cur_out, int* __restrict__ tmp_in, int* __restrict__ tmp_out) {
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (e >= n_edges) return;
+    const int s = static_cast<int>(ei[e]), d = static_cast<int>(ei[n_edges + e]);
+    tmp_in[atomicAdd(&cur_in[d], 1)] = static_cast<int>(e);
+    tmp_out[atomicAdd(&cur_out[s], 1)] = static_cast<int>(e);
+}
+
+// The atomic fill leaves each row's edge ids in arrival order; sorting them (unique ints) makes
+// the CSR -- and every floating-point sum over a row -- deterministic.
+// Rows of <= 64 entries: one wave, bitonic network through lane shuffles.
+__global__ void __launch_bounds__(kT) sort_rows_wave(const int* __restrict__ in_ptr, const int* __restrict__ out_ptr, int64_t N,
+                                                    const int* __restrict__ tmp_in, const int* __restrict__ tmp_out,
+                                                    const int64_t* __restrict__ ei, int64_t n_edges, int* __restrict__ in_eid,
+                                                    int* __restrict__ in_src, int* __restrict__ out_eid,
+                                                    int* __restrict__ out_dst) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
+    if (r >= 2 * N) return;
+    const bool out = r >= N;
+    const int64_t row = out ? r - N : r;
+    const int* ptr = out ? out_ptr : in_ptr;
+    const int base = ptr[row], d = ptr[row + 1] - base;
+    if (d == 0 || d > 64) return;
+    const int* tmp = out ? tmp_out : tmp_in;
+    int v = lane < d ? tmp[base + lane] : 0x7fffffff;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int o = __shfl_xor(v, j, 64);
+            const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+            v = keep_min ? min(v, o) : max(v, o);
+        }
+    }
+    if (lane < d) {
+        if (out) { out_eid[base + lane] = v; out_dst[base + lane] = static_cast<int>(ei[n_edges + v]); }
+        else     { in_eid[base + lane] = v;  in_src[base + lane] = static_cast<int>(ei[v]); }
+    }
+}
+
+// Rows of > 64 entries: one block per row; bitonic sort in LDS up to kMaxLdsRow entries,
+// rank-by-counting straight from L2 beyond that (hub rows).
+__global__ void __launch_bounds__(kT) sort_rows_block(const int* __restrict__ in_ptr, const int* __restrict__ out_ptr, int64_t N,
+                                                     const int* __restrict__ tmp_in, const int* __restrict__ tmp_out,
+                                                     const int64_t* __restrict__ ei, int64_t n_edges, int* __restrict__ in_eid,
+                                                     int* __restrict__ in_src, int* __restrict__ out_eid,
+                                                     int* __restrict__ out_dst) {
+    __shared__ int a[kMaxLdsRow];
+    const int64_t r = blockIdx.x;
+    const bool out = r >= N;
+    const int64_t row = out ? r - N : r;
+    const int* ptr = out ? out_ptr : in_ptr;
+    const int base = ptr[row], d = ptr[row + 1] - base;
+    if (d <= 64) return;
+    const int* tmp = (out ? tmp_out : tmp_in) + base;
+    int* eid_o = (out ? out_eid : in_eid) + base;
+    int* col_o = (out ? out_dst : in_src) + base;
+    const int64_t* colsrc = out ? ei + n_edges : ei;
+    if (d <= kMaxLdsRow) {
+        int n2 = 128;
+        while (n2 < d) n2 <<= 1;
+        for (int i = threadIdx.x; i < n2; i += kT) a[i] = i < d ? tmp[i] : 0x7fffffff;
+        __syncthreads();
+        for (int k = 2; k <= n2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int idx = threadIdx.x; idx < (n2 >> 1); idx += kT) {
+                    const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
+                    const int p = i | j;
+                    const int x = a[i], y = a[p];
+                    const bool asc = (i & k) == 0;
+                    if ((x > y) == asc) { a[i] = y; a[p] = x; }
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = threadIdx.x; i < d; i += kT) {
+            const int v = a[i];
+            eid_o[i] = v;
+            col_o[i] = static_cast<int>(colsrc[v]);
+        }
+    } else {
+        for (int i = threadIdx.x; i < d; i += kT) {
+            const int v = tmp[i];
+            int rank = 0;
+            for (int j = 0; j < d; ++j) rank += (tmp[j] < v);
+            eid_o[rank] = v;
+            col_o[rank] = static_cast<int>(colsrc[v]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- gcn_norm forward
+// One wave per node: deg_i = loopw_i + sum_{k in in-row i, src != i} w[eid_k]; dis = deg^-1/2.
+__global__ void __launch_bounds__(kT) norm_deg(const float* __restrict__ w, int64_t N, const int* __restrict__ in_ptr,
+                                              const int* __restrict__ in_src, const int* __restrict__ in_eid,
+                                              const int* __restrict__ loop_eid, float* __restrict__ dis,
+                                              float* __restrict__ loopw) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
+    if (i >= N) return;
+    const int b = in_ptr[i], e = in_ptr[i + 1];
+    float acc = 0.f;
+    for (int k = b + lane; k < e; k += 64) {
+        if (in_src[k] != static_cast<int>(i)) acc += w ? w[in_eid[k]] : 1.0f;
+    }
+    acc = wave_sum_all(acc);
+    const int le = loop_eid[i];
+    const float lw = (le >= 0 && w) ? w[le] : 1.0f;
+    const float deg = lw + acc;
+    float di = 1.0f / sqrtf(deg);           // deg.pow(-0.5)
+    if (isinf(di)) di = 0.f;                // masked_fill(inf -> 0)
+    if (lane == 0) { dis[i] = di; loopw[i] = lw; }
+}
+
+// Normalised weights in both CSR orders (0 for loop entries, which the loop term replaces).
+__global__ void __launch_bounds__(kT) norm_weights(const float* __restrict__ w, int64_t N, int64_t n_edges,
+                                                  const int* __restrict__ in_ptr, const int* __restrict__ in_src,
+                                                  const int* __restrict__ in_eid, const int* __restrict__ out_ptr,
+                                                  const int* __restrict__ out_dst, const int* __restrict__ out_eid,
+                                                  const float* __restrict__ dis, const float* __restrict__ loopw,
+                                                  float* __restrict__ what_in, float* __restrict__ what_out,
+                                                  float* __restrict__ what_loop) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
+    if (r >= 2 * N) return;
+    const bool out = r >= N;
+    const int i = static_cast<int>(out ? r - N : r);
+    const float di = dis[i];
+    if (!out) {
+        const int b = in_ptr[i], e = in_ptr[i + 1];
+        for (int k = b + lane; k < e; k += 64) {
+            const int s = in_src[k];
+            const float we = w ? w[in_eid[k]] : 1.0f;
+            what_in[k] = (s == i) ? 0.f : (dis[s] * we) * di;     // dis[row] * w * dis[col]
+        }
+        if (lane == 0) what_loop[i] = (di * loopw[i]) * di;
+    } else {
+        const int b = out_ptr[i], e = out_ptr[i + 1];
+        for (int k = b + lane; k < e; k += 64) {
+            const int t = out_dst[k];
+            const float we = w ? w[out_eid[k]] : 1.0f;
+            what_out[k] = (t == i) ? 0.f : (di * we) * dis[t];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- gcn_norm backward
+__global__ void __launch_bounds__(kT) norm_bwd_node(const float* __restrict__ w, const float* __restrict__ gw,
+                                                   const float* __restrict__ gloop, int64_t N, const int* __restrict__ in_ptr,
+                                                   const int* __restrict__ in_src, const int* __restrict__ in_eid,
+                                                   const int* __restrict__ out_ptr, const int* __restrict__ out_dst,
+                                                   const int* __restrict__ out_eid, const float* __restrict__ dis,
+                                                   const float* __restrict__ loopw, float* __restrict__ Hn) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
+    if (t >= N) return;
+    float acc = 0.f;
+    for (int k = in_ptr[t] + lane; k < in_ptr[t + 1]; k += 64) {
+        const int s = in_src[k];
+        if (s != static_cast<int>(t)) { const int e = in_eid[k]; acc += gw[e] * w[e] * dis[s]; }
+    }
+    for (int k = out_ptr[t] + lane; k < out_ptr[t + 1]; k += 64) {
+        const int d = out_dst[k];
+        if (d != static_cast<int>(t)) { const int e = out_eid[k]; acc += gw[e] * w[e] * dis[d]; }
+    }
+    acc = wave_sum_all(acc);
+    if (lane == 0) {
+        const float a = dis[t];
+        const float G = acc + 2.0f * gloop[t] * loopw[t] * a;
+        Hn[t] = -0.5f * a * a * a * G;
+    }
+}
+
+__global__ void __launch_bounds__(kT) norm_bwd_edge(const float* __restrict__ gw, const float* __restrict__ gloop,
+                                                   const int64_t* __restrict__ ei, int64_t n_edges,
+                                                   const int* __restrict__ loop_eid, const float* __restrict__ dis,
+                                                   const float* __restrict__ Hn, float* __restrict__ dw) {
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (e >= n_edges) return;
+    const int s = static_cast<int>(ei[e]), t = static_cast<int>(ei[n_edges + e]);
+    float g;
+    if (s != t) g = gw[e] * dis[s] * dis[t] + Hn[t];
+    else g = gloop[s] * dis[s] * dis[s] + Hn[s];   // every existing (i,i) edge: PyG's index_put backward hands
+                                                   // the loop gradient to overwritten duplicates too
+    dw[e] = g;
+}
+
+// ---------------------------------------------------------------- CSR SpMM:  Y[i,:] = act( sum_k val[k] X[col[k],:] + diag[i] X[i,:] + bias )
+// A group of LPR lanes owns one output row and walks its CSR row; each lane holds VEC
+// consecutive columns per column chunk.  Gathered X rows come from L2/Infinity Cache at
+// partition scale; the per-row (col, val) stream is a wave-uniform broadcast read.
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<4> { using type = float4; };
+
+__device__ __forceinline__ void fma_vec(float& a, float w, float x) { a = fmaf(w, x, a); }
+__device__ __forceinline__ void fma_vec(float4& a, float w, const float4& x) {
+    a.x = fmaf(w, x.x, a.x); a.y = fmaf(w, x.y, a.y); a.z = fmaf(w, x.z, a.z); a.w = fmaf(w, x.w, a.w);
+}
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <int VEC, int LPR>
+__global__ void __launch_bounds__(kT) spmm_csr(const float* __restrict__ X, int64_t N, int64_t D, const int* __restrict__ ptr,
+                                              const int* __restrict__ col, const float* __restrict__ val,
+                                              const float* __restrict__ diag, const float* __restrict__ bias, int act,
+                                              float drop_scale, uint32_t drop_thresh, uint64_t seed, uint32_t site,
+                                              float* __restrict__ Y) {
+    using V = typename VecT<VEC>::type;
+    constexpr int RPB = kT / LPR;   // rows per block
+    const int sub = threadIdx.x % LPR;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * RPB + threadIdx.x / LPR;
+    if (i >= N) return;
+    const int b = ptr[i], e = ptr[i + 1];
+    const float dg = diag ? diag[i] : 0.f;
+    for (int64_t c0 = static_cast<int64_t>(sub) * VEC; c0 < D; c0 += static_cast<int64_t>(LPR) * VEC) {
+        V acc;
+        if (VEC == 4) *reinterpret_cast<float4*>(&acc) = zero4(); else *reinterpret_cast<float*>(&acc) = 0.f;
+        int k = b;
+        for (; k + 4 <= e; k += 4) {          // 4 independent row gathers in flight
+            const int j0 = col[k], j1 = col[k + 1], j2 = col[k + 2], j3 = col[k + 3];
+            const float w0 = val[k], w1 = val[k + 1], w2 = val[k + 2], w3 = val[k + 3];
+            const V x0 = *reinterpret_cast<const V*>(X + static_cast<int64_t>(j0) * D + c0);
+            const V x1 = *reinterpret_cast<const V*>(X + static_cast<int64_t>(j1) * D + c0);
+            const V x2 = *reinterpret_cast<const V*>(X + static_cast<int64_t>(j2) * D + c0);
+            const V x3 = *reinterpret_cast<const V*>(X + static_cast<int64_t>(j3) * D + c0);
+            fma_vec(acc, w0, x0); fma_vec(acc, w1, x1); fma_vec(acc, w2, x2); fma_vec(acc, w3, x3);
+        }
+        for (; k < e; ++k) {
+            const V x0 = *reinterpret_cast<const V*>(X + static_cast<int64_t>(col[k]) * D + c0);
+            fma_vec(acc, val[k], x0);
+        }
+        if (diag) {
+            const V xi = *reinterpret_cast<const V*>(X + i * D + c0);
+            fma_vec(acc, dg, xi);
+        }
+        float o[VEC];
+        *reinterpret_cast<V*>(o) = acc;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float y = o[v];
+            if (bias) y += bias[c0 + v];
+            if (act != SGS_ACT_NONE) y = fmaxf(y, 0.f);
+            if (act == SGS_ACT_RELU_DROPOUT)
+                y = dropout_keep_at(seed, site, static_cast<uint64_t>(i), static_cast<uint32_t>(c0 + v), drop_thresh)
+                        ? y * drop_scale : 0.f;
+            o[v] = y;
+        }
+        *reinterpret_cast<V*>(Y + i * D + c0) = *reinterpret_cast<V*>(o);
+    }
+}
+
+// SDDMM over the CSR: g[eid[k]] = <A[i,:], B[col[k],:]> for k in row i ; gdiag[i] = <A[i,:], B[i,:]>.
+template <int VEC, int LPR>
+__global__ void __launch_bounds__(kT) sddmm_csr(const float* __restrict__ A, const float* __restrict__ B, int64_t N, int64_t D,
+                                               const int* __restrict__ ptr, const int* __restrict__ col,
+                                               const int* __restrict__ eid, float* __restrict__ g, float* __restrict__ gdiag) {
+    using V = typename VecT<VEC>::type;
+    constexpr int RPB = kT / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * RPB + threadIdx.x / LPR;
+    const bool live = i < N;            // keep every lane in the shuffles
+    const int b = live ? ptr[i] : 0, e = live ? ptr[i + 1] : 0;
+    // rows of one LPR-group advance together; groups in a wave may have different trip counts,
+    // so the loop bound is made wave-uniform (max over the wave) and dead lanes contribute 0.
+    int trips = e - b + 1;             // +1: the diagonal term
+    for (int o = 32; o > 0; o >>= 1) trips = max(trips, __shfl_xor(trips, o, 64));
+    for (int t = 0; t < trips; ++t) {
+        const int k = b + t;
+        const bool is_edge = live && k < e;
+        const bool is_diag = live && k == e;
+        const int64_t j = is_edge ? col[k] : i;
+        float acc = 0.f;
+        if (is_edge || is_diag) {
+            for (int64_t c0 = static_cast<int64_t>(sub) * VEC; c0 < D; c0 += static_cast<int64_t>(LPR) * VEC) {
+                float a[VEC], x[VEC];
+                *reinterpret_cast<V*>(a) = *reinterpret_cast<const V*>(A + i * D + c0);
+                *reinterpret_cast<V*>(x) = *reinterpret_cast<const V*>(B + j * D + c0);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc = fmaf(a[v], x[v], acc);
+            }
+        }
+#pragma unroll
+        for (int o = LPR >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (sub == 0) {
+            if (is_edge) g[eid[k]] = acc;
+            else if (is_diag && gdiag) gdiag[i] = acc;
+        }
+    }
+}
+
+// dZ = dY * act'(Y):  ReLU -> [Y > 0];  ReLU+dropout -> [Y > 0] / (1 - p)  (Y > 0 iff kept and positive).
+__global__ void __launch_bounds__(kT) act_bwd(const float* __restrict__ dY, const float* __restrict__ Y, int64_t n, int act,
+                                             float drop_scale, float* __restrict__ dZ) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (i >= n) return;
+    float g = dY[i];
+    if (act != SGS_ACT_NONE) g = (Y[i] > 0.f) ? (act == SGS_ACT_RELU_DROPOUT ? g * drop_scale : g) : 0.f;
+    dZ[i] = g;
+}
+
+// Column sums of a [N, D] matrix (bias gradient): one block per 64 columns, fixed row order.
+__global__ void __launch_bounds__(kT) colsum(const float* __restrict__ A, int64_t N, int64_t D, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rgrp = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < D)
+        for (int64_t r = rgrp; r < N; r += 4) acc += A[r * D + c];
+    red[rgrp][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rgrp == 0 && c < D) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+inline int pick_lpr(int64_t D, int vec) {
+    const int64_t need = (D + vec - 1) / vec;
+    int lpr = 1;
+    while (lpr < need && lpr < 64) lpr <<= 1;
+    return lpr;
+}
+
+}  // namespace
+}  // namespace sgs
+
+using namespace sgs;
+
+#define DISPATCH_VEC_LPR(KERNEL, vec, lpr, grid_rows, ...)                                                       \
+    do {                                                                                                          \
+        const int _rpb = kT / (lpr);                                                                              \
+        const dim3 _g(static_cast<unsigned>(cdiv((grid_rows), _rpb))), _b(kT);                                    \
+        if ((vec) == 4) {                                                                                         \
+            switch (lpr) {                                                                                        \
+                case 1: hipLaunchKernelGGL((KERNEL<4, 1>), _g, _b, 0, stream, __VA_ARGS__); break;                \
+                case 2: hipLaunchKernelGGL((KERNEL<4, 2>), _g, _b, 0, stream, __VA_ARGS__); break;                \
+                case 4: hipLaunchKernelGGL((KERNEL<4, 4>), _g, _b, 0, stream, __VA_ARGS__); break;                \
+                case 8: hipLaunchKernelGGL((KERNEL<4, 8>), _g, _b, 0, stream, __VA_ARGS__); break;                \
+                case 16: hipLaunchKernelGGL((KERNEL<4, 16>), _g, _b, 0, stream, __VA_ARGS__); break;              \
+                case 32: hipLaunchKernelGGL((KERNEL<4, 32>), _g, _b, 0, stream, __VA_ARGS__); break;              \
+                default: hipLaunchKernelGGL((KERNEL<4, 64>), _g, _b, 0, stream, __VA_ARGS__); break;              \
+            }                                                                                                     \
+        } else {                                                                                                  \
+            switch (lpr) {                                                                                        \
+                case 1: hipLaunchKernelGGL((KERNEL<1, 1>), _g, _b, 0, stream, __VA_ARGS__); break;                \
+                case 2: hipLaunchKernelGGL((KERNEL<1, 2>), _g, _b, 0, stream, __VA_ARGS__); break;                \
+                case 4: hipLaunchKernelGGL((KERNEL<1, 4>), _g, _b, 0, stream, __VA_ARGS__); break;                \
+                case 8: hipLaunchKernelGGL((KERNEL<1, 8>), _g, _b, 0, stream, __VA_ARGS__); break;                \
+                case 16: hipLaunchKernelGGL((KERNEL<1, 16>), _g, _b, 0, stream, __VA_ARGS__); break;              \
+                case 32: hipLaunchKernelGGL((KERNEL<1, 32>), _g, _b, 0, stream, __VA_ARGS__); break;              \
+                default: hipLaunchKernelGGL((KERNEL<1, 64>), _g, _b, 0, stream, __VA_ARGS__); break;              \
+            }                                                                                                     \
+        }                                                                                                         \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" {
+
+size_t sgs_graph_build_workspace_bytes(int64_t n_edges, int64_t N) {
+    if (n_edges < 0) n_edges = 0;
+    if (N < 0) N = 0;
+    return 4 * carve_bytes(N + 1, 4) + 2 * carve_bytes(n_edges + 1, 4) + 256;
+}
+
+int sgs_graph_build(const int64_t* edge_index, int64_t n_edges, int64_t N, int32_t* in_ptr, int32_t* in_src,
+                    int32_t* in_eid, int32_t* out_ptr, int32_t* out_dst, int32_t* out_eid, int32_t* loop_eid, void* ws,
+                    size_t ws_bytes, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(n_edges >= 0 && N >= 0 && n_edges < (int64_t(1) << 31) && N < (int64_t(1) << 31), SGS_EINVAL,
+                "sgs_graph_build: sizes out of range (n_edges=%lld N=%lld)", (long long)n_edges, (long long)N);
+    if (N == 0) return SGS_OK;
+    SGS_REQUIRE(in_ptr && out_ptr && loop_eid && (n_edges == 0 || (edge_index && in_src && in_eid && out_dst && out_eid)),
+                SGS_EINVAL, "sgs_graph_build: null pointer");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_graph_build_workspace_bytes(n_edges, N), SGS_EWORKSPACE,
+                "sgs_graph_build: workspace too small");
+    Carver cv(ws);
+    int* cnt_in = cv.take<int>(N + 1);
+    int* cnt_out = cv.take<int>(N + 1);
+    int* cur_in = cv.take<int>(N + 1);
+    int* cur_out = cv.take<int>(N + 1);
+    int* tmp_in = cv.take<int>(n_edges + 1);
+    int* tmp_out = cv.take<int>(n_edges + 1);
+    SGS_HIP_OK(hipMemsetAsync(cnt_in, 0, 2 * carve_bytes(N + 1, 4), stream));      // cnt_in + cnt_out are adjacent
+    SGS_HIP_OK(hipMemsetAsync(loop_eid, 0xff, static_cast<size_t>(N) * 4, stream));  // -1
+    if (n_edges > 0)
+        hipLaunchKernelGGL(count_degrees, dim3(cdiv(n_edges, kT)), dim3(kT), 0, stream, edge_index, n_edges, cnt_in, cnt_out,
+                           loop_eid);
+    hipLaunchKernelGGL(scan_counts, dim3(2), dim3(1024), 0, stream, cnt_in, cnt_out, N, in_ptr, out_ptr, cur_in, cur_out);
+    if (n_edges > 0) {
+        hipLaunchKernelGGL(fill_rows, dim3(cdiv(n_edges, kT)), dim3(kT), 0, stream, edge_index, n_edges, cur_in, cur_out,
+                           tmp_in, tmp_out);
+        hipLaunchKernelGGL(sort_rows_wave, dim3(cdiv(2 * N * 64, kT)), dim3(kT), 0, stream, in_ptr, out_ptr, N, tmp_in,
+                           tmp_out, edge_index, n_edges, in_eid, in_src, out_eid, out_dst);
+        hipLaunchKernelGGL(sort_rows_block, dim3(2 * N), dim3(kT), 0, stream, in_ptr, out_ptr, N, tmp_in, tmp_out, edge_index,
+                           n_edges, in_eid, in_src, out_eid, out_dst);
+    }
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_gcn_norm_fwd(const float* w, int64_t n_edges, int64_t N, const int32_t* in_ptr, const int32_t* in_src,
+                     const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
+                     const int32_t* loop_eid, float* dis, float* loopw, float* what_in, float* what_out, float* what_loop,
+                     sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && n_edges >= 0, SGS_EINVAL, "sgs_gcn_norm_fwd: bad sizes");
+    if (N == 0) return SGS_OK;
+    SGS_REQUIRE(in_ptr && out_ptr && loop_eid && dis && loopw && what_loop, SGS_EINVAL, "sgs_gcn_norm_fwd: null pointer");
+    hipLaunchKernelGGL(norm_deg, dim3(cdiv(N * 64, kT)), dim3(kT), 0, stream, w, N, in_ptr, in_src, in_eid, loop_eid, dis, loopw);
+    hipLaunchKernelGGL(norm_weights, dim3(cdiv(2 * N * 64, kT)), dim3(kT), 0, stream, w, N, n_edges, in_ptr, in_src, in_eid,
+                       out_ptr, out_dst, out_eid, dis, loopw, what_in, what_out, what_loop);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+size_t sgs_gcn_norm_bwd_workspace_bytes(int64_t N) { return carve_bytes(N < 0 ? 0 : N, 4) + 256; }
+
+int sgs_gcn_norm_bwd(const float* w, const float* gw_hat, const float* gloop, int64_t n_edges, int64_t N,
+                     const float* dis, const float* loopw, const int32_t* in_ptr, const int32_t* in_src,
+                     const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
+                     const int32_t* loop_eid, const int64_t* edge_index, float* dw, void* ws, size_t ws_bytes,
+                     sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && n_edges >= 0, SGS_EINVAL, "sgs_gcn_norm_bwd: bad sizes");
+    if (N == 0 || n_edges == 0) return SGS_OK;
+    SGS_REQUIRE(w && gw_hat && gloop && dis && loopw && dw && edge_index, SGS_EINVAL, "sgs_gcn_norm_bwd: null pointer");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_gcn_norm_bwd_workspace_bytes(N), SGS_EWORKSPACE, "sgs_gcn_norm_bwd: workspace too small");
+    Carver cv(ws);
+    float* Hn = cv.take<float>(N);
+    hipLaunchKernelGGL(norm_bwd_node, dim3(cdiv(N * 64, kT)), dim3(kT), 0, stream, w, gw_hat, gloop, N, in_ptr, in_src, in_eid,
+                       out_ptr, out_dst, out_eid, dis, loopw, Hn);
+    hipLaunchKernelGGL(norm_bwd_edge, dim3(cdiv(n_edges, kT)), dim3(kT), 0, stream, gw_hat, gloop, edge_index, n_edges, loop_eid,
+                       dis, Hn, dw);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_spmm_csr(const float* X, int64_t N, int64_t D, const int32_t* ptr, const int32_t* col, const float* val,
+                 const float* diag, const float* bias, int act, float p_drop, uint64_t seed, uint32_t site, float* Y,
+                 sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && D >= 0, SGS_EINVAL, "sgs_spmm_csr: bad sizes");
+    SGS_REQUIRE(act >= SGS_ACT_NONE && act <= SGS_ACT_RELU_DROPOUT && p_drop >= 0.f && p_drop < 1.f, SGS_EINVAL,
+                "sgs_spmm_csr: bad activation / dropout");
+    if (N == 0 || D == 0) return SGS_OK;
+    SGS_REQUIRE(X && ptr && Y && X != Y, SGS_EINVAL, "sgs_spmm_csr: null or aliased pointer");
+    const int vec = (D % 4 == 0 && aligned16(X) && aligned16(Y)) ? 4 : 1;
+    const int lpr = pick_lpr(D, vec);
+    const float scale = 1.0f / (1.0f - p_drop);
+    const uint32_t th = dropout_thresh(p_drop);
+    if (act == SGS_ACT_RELU_DROPOUT && p_drop == 0.f) act = SGS_ACT_RELU;
+    DISPATCH_VEC_LPR(spmm_csr, vec, lpr, N, X, N, D, ptr, col, val, diag, bias, act, scale, th, seed, site, Y);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_sddmm_csr(const float* A, const float* B, int64_t N, int64_t D, const int32_t* ptr, const int32_t* col,
+                  const int32_t* eid, float* g, float* gdiag, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && D >= 0, SGS_EINVAL, "sgs_sddmm_csr: bad sizes");
+    if (N == 0) return SGS_OK;
+    SGS_REQUIRE(A && B && ptr, SGS_EINVAL, "sgs_sddmm_csr: null pointer");
+    const int vec = (D % 4 == 0 && aligned16(A) && aligned16(B)) ? 4 : 1;
+    const int lpr = pick_lpr(D, vec);
+    DISPATCH_VEC_LPR(sddmm_csr, vec, lpr, N, A, B, N, D, ptr, col, eid, g, gdiag);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_act_bwd(const float* dY, const float* Y, int64_t n, int act, float p_drop, float* dZ, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(n >= 0 && p_drop >= 0.f && p_drop < 1.f, SGS_EINVAL, "sgs_act_bwd: bad arguments");
+    if (n == 0) return SGS_OK;
+    SGS_REQUIRE(dY && dZ && (act == SGS_ACT_NONE || Y), SGS_EINVAL, "sgs_act_bwd: null pointer");
+    if (act == SGS_ACT_RELU_DROPOUT && p_drop == 0.f) act = SGS_ACT_RELU;
+    hipLaunchKernelGGL(act_bwd, dim3(cdiv(n, kT)), dim3(kT), 0, stream, dY, Y, n, act, 1.0f / (1.0f - p_drop), dZ);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && D >= 0, SGS_EINVAL, "sgs_colsum: bad sizes");
+    if (D == 0) return SGS_OK;
+    SGS_REQUIRE(A && out, SGS_EINVAL, "sgs_colsum: null pointer");
+    hipLaunchKernelGGL(colsum, dim3(cdiv(D, 64)), dim3(kT), 0, stream, A, N, D, out);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,273 @@
+// K6: gate and losses of the hybrid / straight-through / two-pass step (gfx950).
+//
+// Reference: training_hybrid.py:92-133 and utils.py:163-169 (`calculate_f1`), 187-211
+// (`consistency_loss`).  The reference copies logits to the host for sklearn's micro-F1, runs
+// two sort-based torch.isin calls and one .item() sync for reg1; here everything stays on the
+// device and every reduction uses a fixed tree (deterministic).
+#include "sgs_common.h"
+
+namespace sgs {
+namespace {
+
+constexpr int kT = 256;
+
+// ---------------------------------------------------------------- gate: #correct argmax on train rows
+// One wave per row; torch.argmax semantics (first maximum wins).
+__global__ void __launch_bounds__(kT) masked_correct(const float* __restrict__ logits, int64_t N, int64_t C,
+                                                    const int64_t* __restrict__ y, const uint8_t* __restrict__ mask,
+                                                    int* __restrict__ correct) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
+    if (i >= N || !mask[i]) return;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int64_t c = lane; c < C; c += 64) {
+        const float v = logits[i * C + c];
+        if (v > best || (v == best && static_cast<int>(c) < bi) || bi == 0x7fffffff) { best = v; bi = static_cast<int>(c); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        atomicAdd(&correct[1], 1);
+        if (static_cast<int64_t>(bi) == y[i]) atomicAdd(&correct[0], 1);
+    }
+}
+
+// ---------------------------------------------------------------- masked cross entropy
+// rowloss[i] = lse_i - logit_i[y_i] on train rows (0 elsewhere); row_lse kept for backward.
+__global__ void __launch_bounds__(kT) ce_rows(const float* __restrict__ logits, int64_t N, int64_t C, const int64_t* __restrict__ y,
+                                             const uint8_t* __restrict__ mask, float* __restrict__ row_lse,
+                                             float* __restrict__ rowloss) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
+    if (i >= N) return;
+    if (!mask[i]) {
+        if (lane == 0) { rowloss[i] = 0.f; row_lse[i] = 0.f; }
+        return;
+    }
+    float mx = -INFINITY;
+    for (int64_t c = lane; c < C; c += 64) mx = fmaxf(mx, logits[i * C + c]);
+    mx = wave_max_all(mx);
+    float s = 0.f;
+    for (int64_t c = lane; c < C; c += 64) s += expf(logits[i * C + c] - mx);
+    s = wave_sum_all(s);
+    const float lse = mx + logf(s);
+    if (lane == 0) {
+        row_lse[i] = lse;
+        rowloss[i] = lse - logits[i * C + y[i]];
+    }
+}
+
+// One block: loss = sum(rowloss) / #train ; n_rows[0] = #train.
+__global__ void __launch_bounds__(1024) ce_final(const float* __restrict__ rowloss, const uint8_t* __restrict__ mask, int64_t N,
+                                                float* __restrict__ loss, int* __restrict__ n_rows) {
+    __shared__ float red[16];
+    __shared__ int redi[16];
+    float acc = 0.f;
+    int cnt = 0;
+    for (int64_t i = threadIdx.x; i < N; i += 1024) { acc += rowloss[i]; cnt += mask[i] ? 1 : 0; }
+    const float r = block_sum(acc, red);
+    cnt = wave_sum_int_all(cnt);
+    if ((threadIdx.x & 63) == 0) redi[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int w = 0; w < 16; ++w) n += redi[w];
+        n_rows[0] = n;
+        loss[0] = r / static_cast<float>(n);     // 0/0 = nan, as torch's mean over an empty selection
+    }
+}
+
+__global__ void __launch_bounds__(kT) ce_bwd(const float* __restrict__ logits, int64_t N, int64_t C, const int64_t* __restrict__ y,
+                                            const uint8_t* __restrict__ mask, const float* __restrict__ row_lse,
+                                            const int* __restrict__ n_rows, const float* __restrict__ grad_loss,
+                                            float* __restrict__ dlogits) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (idx >= N * C) return;
+    const int64_t i = idx / C, c = idx - i * C;
+    float g = 0.f;
+    if (mask[i]) {
+        const float sm = expf(logits[idx] - row_lse[i]);
+        g = (sm - (y[i] == c ? 1.f : 0.f)) * (grad_loss[0] / static_cast<float>(n_rows[0]));
+    }
+    dlogits[idx] = g;
+}
+
+// ---------------------------------------------------------------- edge regularisers
+struct EdgeTerms {
+    float dot, nx, ny;   // <x,y>, |x|^2, |y|^2
+};
+__device__ __forceinline__ EdgeTerms edge_dot(const float* __restrict__ x, const float* __restrict__ y, int64_t C) {
+    EdgeTerms t{0.f, 0.f, 0.f};
+    for (int64_t c = 0; c < C; ++c) {
+        const float a = x[c], b = y[c];
+        t.dot = fmaf(a, b, t.dot); t.nx = fmaf(a, a, t.nx); t.ny = fmaf(b, b, t.ny);
+    }
+    return t;
+}
+// F.cosine_similarity(x, y, eps=1e-8) = <x,y> / sqrt(max(|x|^2 |y|^2, eps^2))
+__device__ __forceinline__ float cos_from(const EdgeTerms& t) { return t.dot / sqrtf(fmaxf(t.nx * t.ny, 1e-16f)); }
+
+// per block partials: [0]=sum bce, [1]=sum (w-cos)^2, [2]=#valid, [3]=sum labels
+__global__ void __launch_bounds__(kT) reg_fwd_partial(const float* __restrict__ w, const int64_t* __restrict__ sei, int64_t q,
+                                                     const float* __restrict__ logits, int64_t C, const int64_t* __restrict__ y,
+                                                     const uint8_t* __restrict__ tm, float* __restrict__ cos_out,
+                                                     float* __restrict__ part) {
+    __shared__ float red[kT / 64];
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    float bce = 0.f, sq = 0.f, nv = 0.f, nl = 0.f;
+    if (j < q) {
+        const int64_t s = sei[j], d = sei[q + j];
+        const float wj = w[j];
+        const float cs = cos_from(edge_dot(logits + s * C, logits + d * C, C));
+        if (cos_out) cos_out[j] = cs;
+        const float df = wj - cs;
+        sq = df * df;
+        if (tm[s] && tm[d]) {
+            nv = 1.f;
+            const bool same = y[s] == y[d];
+            nl = same ? 1.f : 0.f;
+            // F.binary_cross_entropy clamps each log at -100
+            bce = same ? -fmaxf(logf(wj), -100.f) : -fmaxf(logf(1.f - wj), -100.f);
+        }
+    }
+    const float r0 = block_sum(bce, red);
+    const float r1 = block_sum(sq, red);
+    const float r2 = block_sum(nv, red);
+    const float r3 = block_sum(nl, red);
+    if (threadIdx.x == 0) {
+        part[4 * blockIdx.x + 0] = r0; part[4 * blockIdx.x + 1] = r1;
+        part[4 * blockIdx.x + 2] = r2; part[4 * blockIdx.x + 3] = r3;
+    }
+}
+
+// out[0] = reg1 (0 unless sum(labels) > 1), out[1] = reg2, out[2] = #valid, out[3] = sum labels,
+// out[4] = coef1 * reg1 + coef2 * reg2
+__global__ void __launch_bounds__(kT) reg_fwd_final(const float* __restrict__ part, int64_t nblk, int64_t q, float coef1, float coef2,
+                                                   float* __restrict__ out) {
+    __shared__ float red[kT / 64];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int64_t b = threadIdx.x; b < nblk; b += kT) {
+        a0 += part[4 * b]; a1 += part[4 * b + 1]; a2 += part[4 * b + 2]; a3 += part[4 * b + 3];
+    }
+    const float r0 = block_sum(a0, red), r1 = block_sum(a1, red), r2 = block_sum(a2, red), r3 = block_sum(a3, red);
+    if (threadIdx.x == 0) {
+        const float reg1 = (r3 > 1.f) ? r0 / r2 : 0.f;             // training_hybrid.py:125-128
+        const float reg2 = r1 / static_cast<float>(q);
+        out[0] = reg1; out[1] = reg2; out[2] = r2; out[3] = r3;
+        out[4] = coef1 * reg1 + coef2 * reg2;
+    }
+}
+
+// Per sampled edge: dw[j] and the gradient rows wrt logits[src] (Gs) and logits[dst] (Gd).
+__global__ void __launch_bounds__(kT) reg_bwd_edges(const float* __restrict__ w, const int64_t* __restrict__ sei, int64_t q,
+                                                   const float* __restrict__ logits, int64_t C, const int64_t* __restrict__ y,
+                                                   const uint8_t* __restrict__ tm, const float* __restrict__ out, float coef1,
+                                                   float coef2, const float* __restrict__ grad_loss, float* __restrict__ dw,
+                                                   float* __restrict__ Gs, float* __restrict__ Gd) {
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (j >= q) return;
+    const float gl = grad_loss[0];
+    const int64_t s = sei[j], d = sei[q + j];
+    const float* x = logits + s * C;
+    const float* yv = logits + d * C;
+    const EdgeTerms t = edge_dot(x, yv, C);
+    const float den2 = fmaxf(t.nx * t.ny, 1e-16f);
+    const float inv = 1.0f / sqrtf(den2);
+    const float cs = t.dot * inv;
+    const float wj = w[j];
+    const float r = 2.0f * (wj - cs) / static_cast<float>(q) * coef2 * gl;        // dL/d(w - cos)
+    float g = r;
+    if (coef1 != 0.f && out[3] > 1.f && tm[s] && tm[d]) {
+        const float tgt = (y[s] == y[d]) ? 1.f : 0.f;
+        g += coef1 * gl * (wj - tgt) / fmaxf((1.f - wj) * wj, 1e-12f) / out[2];   // torch's BCE backward
+    }
+    dw[j] = g;
+    // d cos / d x = y * inv - cos * x / |x|^2  (only while the eps clamp is inactive, as autograd)
+    const bool clamped = t.nx * t.ny < 1e-16f;
+    const float cx = clamped ? 0.f : cs / t.nx, cy = clamped ? 0.f : cs / t.ny;
+    for (int64_t c = 0; c < C; ++c) {
+        const float a = x[c], b = yv[c];
+        Gs[j * C + c] = -r * (b * inv - cx * a);
+        Gd[j * C + c] = -r * (a * inv - cy * b);
+    }
+}
+
+}  // namespace
+}  // namespace sgs
+
+using namespace sgs;
+
+extern "C" {
+
+int sgs_masked_correct(const float* logits, int64_t N, int64_t C, const int64_t* y, const uint8_t* train_mask,
+                       int32_t* correct, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && C > 0 && correct, SGS_EINVAL, "sgs_masked_correct: bad arguments");
+    SGS_HIP_OK(hipMemsetAsync(correct, 0, 8, stream));
+    if (N == 0) return SGS_OK;
+    SGS_REQUIRE(logits && y && train_mask, SGS_EINVAL, "sgs_masked_correct: null pointer");
+    hipLaunchKernelGGL(masked_correct, dim3(cdiv(N * 64, kT)), dim3(kT), 0, stream, logits, N, C, y, train_mask, correct);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_masked_ce_fwd(const float* logits, int64_t N, int64_t C, const int64_t* y, const uint8_t* train_mask, float* loss,
+                      float* row_lse, float* rowloss, int32_t* n_rows, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N > 0 && C > 0 && logits && y && train_mask && loss && row_lse && rowloss && n_rows, SGS_EINVAL,
+                "sgs_masked_ce_fwd: bad arguments");
+    hipLaunchKernelGGL(ce_rows, dim3(cdiv(N * 64, kT)), dim3(kT), 0, stream, logits, N, C, y, train_mask, row_lse, rowloss);
+    hipLaunchKernelGGL(ce_final, dim3(1), dim3(1024), 0, stream, rowloss, train_mask, N, loss, n_rows);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_masked_ce_bwd(const float* logits, int64_t N, int64_t C, const int64_t* y, const uint8_t* train_mask,
+                      const float* row_lse, const int32_t* n_rows, const float* grad_loss, float* dlogits,
+                      sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N > 0 && C > 0 && logits && y && train_mask && row_lse && n_rows && grad_loss && dlogits, SGS_EINVAL,
+                "sgs_masked_ce_bwd: bad arguments");
+    hipLaunchKernelGGL(ce_bwd, dim3(cdiv(N * C, kT)), dim3(kT), 0, stream, logits, N, C, y, train_mask, row_lse, n_rows, grad_loss,
+                       dlogits);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+size_t sgs_edge_reg_workspace_bytes(int64_t q) { return carve_bytes(4 * (cdiv(q < 0 ? 0 : q, kT) + 1), 4) + 256; }
+
+int sgs_edge_reg_fwd(const float* w, const int64_t* sampled_edge_index, int64_t q, const float* logits, int64_t N, int64_t C,
+                     const int64_t* y, const uint8_t* train_mask, float coef1, float coef2, float* out, float* cos_out,
+                     void* ws, size_t ws_bytes, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(q > 0 && N > 0 && C > 0 && w && sampled_edge_index && logits && y && train_mask && out, SGS_EINVAL,
+                "sgs_edge_reg_fwd: bad arguments");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_reg_workspace_bytes(q), SGS_EWORKSPACE, "sgs_edge_reg_fwd: workspace too small");
+    Carver cv(ws);
+    const int64_t nblk = cdiv(q, kT);
+    float* part = cv.take<float>(4 * (nblk + 1));
+    hipLaunchKernelGGL(reg_fwd_partial, dim3(nblk), dim3(kT), 0, stream, w, sampled_edge_index, q, logits, C, y, train_mask, cos_out,
+                       part);
+    hipLaunchKernelGGL(reg_fwd_final, dim3(1), dim3(kT), 0, stream, part, nblk, q, coef1, coef2, out);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_edge_reg_bwd(const float* w, const int64_t* sampled_edge_index, int64_t q, const float* logits, int64_t N, int64_t C,
+                     const int64_t* y, const uint8_t* train_mask, const float* out, float coef1, float coef2,
+                     const float* grad_loss, float* dw, float* Gs, float* Gd, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(q > 0 && N > 0 && C > 0 && w && sampled_edge_index && logits && y && train_mask && out && grad_loss && dw && Gs && Gd,
+                SGS_EINVAL, "sgs_edge_reg_bwd: bad arguments");
+    hipLaunchKernelGGL(reg_bwd_edges, dim3(cdiv(q, kT)), dim3(kT), 0, stream, w, sampled_edge_index, q, logits, C, y, train_mask, out,
+                       coef1, coef2, grad_loss, dw, Gs, Gd);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+// Shared host/device helpers for libsgs_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/sgs_hip.h"
+
+namespace sgs {
+
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------- errors (thread-local message)
+void set_error(const char* fmt, ...);
+
+#define SGS_REQUIRE(cond, code, ...)      \
+    do {                                  \
+        if (!(cond)) {                    \
+            ::sgs::set_error(__VA_ARGS__); \
+            return (code);                \
+        }                                 \
+    } while (0)
+
+#define SGS_HIP_OK(expr)                                                                  \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            ::sgs::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return SGS_EHIP;                                                              \
+        }                                                                                 \
+    } while (0)
+
+#define SGS_LAUNCH_OK()                                                                   \
+    do {                                                                                  \
+        hipError_t _e = hipGetLastError();                                                \
+        if (_e != hipSuccess) {                                                           \
+            ::sgs::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return SGS_EHIP;                                                              \
+        }                                                                                 \
+    } while (0)
+
+// ---------------------------------------------------------------- workspace carving (256-B aligned)
+struct Carver {
+    char* base;
+    size_t off;
+    explicit Carver(void* p) : base(static_cast<char*>(p)), off(0) {}
+    template <typename T>
+    T* take(size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+        T* r = reinterpret_cast<T*>(base + off);
+        off += bytes;
+        return r;
+    }
+};
+inline size_t carve_bytes(size_t n, size_t elem) { return (n * elem + 255) & ~size_t(255); }
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- device: wave / block reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;  // valid in lane 0
+}
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max_all(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_int_all(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Deterministic block sum (fixed tree): result valid in thread 0.  `red` needs blockDim/64 floats.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) r += red[i];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_max_all(v);
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
+    __syncthreads();
+    return r;  // valid in every thread
+}
+
+// ---------------------------------------------------------------- counter-based RNG
+// Philox4x32-10 (Salmon et al. 2011).  Integer-only, so host restatements reproduce it exactly.
+struct Philox4 {
+    uint32_t v[4];
+};
+__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) {
+    return static_cast<uint32_t>((static_cast<uint64_t>(a) * b) >> 32);
+}
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                          uint32_t k0, uint32_t k1) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = mulhi32(M0, c0), lo0 = M0 * c0;
+        uint32_t hi1 = mulhi32(M1, c2), lo1 = M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    return Philox4{{c0, c1, c2, c3}};
+}
+
+// Exp(1) draw number `e` of stream (seed, stream_id): u = (k + 1/2) 2^-23, k = 23 random bits, so
+// u is exact in fp32 and lies in [2^-24, 1 - 2^-24] (never 0 or 1); noise = -log(u) in (0, 16.7).
+__device__ __forceinline__ float exp_noise_at(uint64_t seed, uint64_t stream_id, uint64_t e) {
+    const uint64_t blk = e >> 2;
+    Philox4 r = philox4x32_10(static_cast<uint32_t>(blk), static_cast<uint32_t>(blk >> 32),
+                              static_cast<uint32_t>(stream_id), static_cast<uint32_t>(stream_id >> 32),
+                              static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
+    const uint32_t x = r.v[e & 3];
+    const float u = (static_cast<float>(x >> 9) + 0.5f) * (1.0f / 8388608.0f);
+    return -logf(u);
+}
+
+// Dropout keep decision for element (row, col) of dropout site `site`: a murmur-style 64-bit
+// finaliser of (seed, site, row, col) compared against p.  Every fused kernel and the
+// materialising sgs_dropout_keep use this one function, so recompute-in-backward sees the
+// same bits as forward.
+__host__ __device__ __forceinline__ uint32_t mix64to32(uint64_t z) {
+    z ^= z >> 33; z *= 0xff51afd7ed558ccdULL;
+    z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ULL;
+    z ^= z >> 33;
+    return static_cast<uint32_t>(z >> 32);
+}
+__host__ __device__ __forceinline__ bool dropout_keep_at(uint64_t seed, uint32_t site, uint64_t row, uint32_t col,
+                                                         uint32_t thresh /* = p * 2^32 */) {
+    uint64_t z = seed ^ (0x9E3779B97F4A7C15ULL * (static_cast<uint64_t>(site) + 1));
+    z = (z ^ row) * 0xD6E8FEB86659FD93ULL;
+    z ^= static_cast<uint64_t>(col) * 0xA24BAED4963EE407ULL;
+    return mix64to32(z) >= thresh;
+}
+__host__ __device__ __forceinline__ uint32_t dropout_thresh(float p) {
+    double t = static_cast<double>(p) * 4294967296.0;
+    if (t < 0) t = 0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return static_cast<uint32_t>(t);
+}
+
+}  // namespace sgs

@@ -1,0 +1,385 @@
+"""Host-side wrappers over the C ABI (include/sgs_hip.h): tensor checks, workspace, stream
+plumbing and the torch.autograd.Function glue.  PyTorch is used for device memory, streams
+and autograd bookkeeping only; every numeric step of the hot path runs in libsgs_hip.so.
+Nothing here computes on the CPU: a non-HIP tensor raises."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+SAMPLE_LEARNED, SAMPLE_PRIOR = 0, 1
+ACT_NONE, ACT_RELU, ACT_RELU_DROPOUT = 0, 1, 2
+
+_workspaces = {}
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("sgs_gnn_amd: the SGS hot path runs only on a HIP device (got a CPU tensor); "
+                               "there is no CPU fallback")
+
+
+def _ptr(t, dtype=None):
+    if t is None:
+        return None
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"sgs_gnn_amd: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError("sgs_gnn_amd: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only per-device scratch arena (stream-ordered reuse on the current stream)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+# ------------------------------------------------------------------ randomness
+def exp_noise(seed: int, stream_id: int, E: int, device) -> torch.Tensor:
+    L = _lib.lib()
+    out = torch.empty(E, dtype=torch.float32, device=device)
+    _need_gpu(out)
+    _lib.check(L.sgs_exp_noise(seed, stream_id, E, _ptr(out), _stream()), "sgs_exp_noise")
+    return out
+
+
+def dropout_keep(seed: int, site: int, rows: int, cols: int, p: float, device) -> torch.Tensor:
+    L = _lib.lib()
+    out = torch.empty(rows, cols, dtype=torch.uint8, device=device)
+    _need_gpu(out)
+    _lib.check(L.sgs_dropout_keep(seed, site, rows, cols, p, _ptr(out), _stream()), "sgs_dropout_keep")
+    return out.bool()
+
+
+# ------------------------------------------------------------------ sampler
+class SampleResult:
+    __slots__ = ("mask", "eid", "edge_index", "p", "stats", "keys", "E", "q")
+
+
+def sample_topq(mode: int, p: torch.Tensor, prior, c: float, q: int, edge_index, noise=None, seed: int = 0,
+                stream_id: int = 0, want_keys: bool = False, want_p: bool = True) -> SampleResult:
+    """K0/K2/K3 (see sgs_sample_topq).  p [E] f32; prior [E] f32 or None; edge_index [2,E] i64."""
+    L = _lib.lib()
+    _need_gpu(p, prior, edge_index, noise)
+    E = p.numel()
+    dev = p.device
+    if q > E:
+        raise RuntimeError(f"cannot sample q={q} > E={E} edges without replacement")
+    r = SampleResult()
+    r.E, r.q = E, q
+    r.mask = torch.empty(E, dtype=torch.bool, device=dev)
+    r.eid = torch.empty(q, dtype=torch.int64, device=dev)
+    r.edge_index = torch.empty(2, q, dtype=torch.int64, device=dev) if edge_index is not None else None
+    r.p = torch.empty(q, dtype=torch.float32, device=dev) if want_p else None
+    r.stats = torch.empty(4, dtype=torch.float32, device=dev)
+    r.keys = torch.empty(E, dtype=torch.float32, device=dev) if want_keys else None
+    nws = L.sgs_sample_topq_workspace_bytes(E)
+    ws = workspace(nws, dev)
+    _lib.check(L.sgs_sample_topq(mode, _ptr(p, torch.float32), _ptr(prior, torch.float32), float(c),
+                                 _ptr(noise, torch.float32), seed, stream_id, E, q, _ptr(edge_index, torch.int64),
+                                 _ptr(r.mask), _ptr(r.eid), _ptr(r.edge_index), _ptr(r.p), _ptr(r.stats),
+                                 _ptr(r.keys), ws.data_ptr(), ws.numel(), _stream()), "sgs_sample_topq")
+    return r
+
+
+class _STWeights(torch.autograd.Function):
+    """sampling.py:137-138,155: clamp(p * ((one_hot - s).detach() + s), 0, 1)[mask]."""
+
+    @staticmethod
+    def forward(ctx, p, prior, c, stats, eid):
+        L = _lib.lib()
+        E, q = p.numel(), eid.numel()
+        w = torch.empty(q, dtype=torch.float32, device=p.device)
+        _lib.check(L.sgs_st_weights_fwd(_ptr(p, torch.float32), _ptr(prior, torch.float32), float(c), _ptr(stats),
+                                        _ptr(eid, torch.int64), E, q, _ptr(w), _stream()), "sgs_st_weights_fwd")
+        ctx.save_for_backward(p, prior if prior is not None else torch.empty(0, device=p.device), stats, eid)
+        ctx.c, ctx.has_prior = float(c), prior is not None
+        return w
+
+    @staticmethod
+    def backward(ctx, gw):
+        L = _lib.lib()
+        p, prior, stats, eid = ctx.saved_tensors
+        prior = prior if ctx.has_prior else None
+        E, q = p.numel(), eid.numel()
+        gw = gw.contiguous()
+        gp = torch.empty(E, dtype=torch.float32, device=p.device)
+        nws = L.sgs_st_weights_bwd_workspace_bytes(E, q)
+        ws = workspace(nws, p.device)
+        _lib.check(L.sgs_st_weights_bwd(_ptr(p), _ptr(prior), ctx.c, _ptr(stats), _ptr(eid), _ptr(gw), E, q, _ptr(gp),
+                                        ws.data_ptr(), ws.numel(), _stream()), "sgs_st_weights_bwd")
+        return gp, None, None, None, None
+
+
+def st_weights(p, prior, c, stats, eid):
+    _need_gpu(p, prior, stats, eid)
+    return _STWeights.apply(p.contiguous(), prior, c, stats, eid)
+
+
+# ------------------------------------------------------------------ graph + GCN
+class Graph:
+    """Both CSR orientations of one edge list (sgs_graph_build).  Built once per sampled graph
+    and shared by every layer / pass that runs over it."""
+
+    def __init__(self, edge_index: torch.Tensor, N: int):
+        L = _lib.lib()
+        _need_gpu(edge_index)
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise RuntimeError("edge_index must be an int64 [2, E] tensor")
+        ei = edge_index.contiguous()
+        dev = ei.device
+        n = ei.shape[1]
+        self.edge_index, self.n_edges, self.N = ei, n, int(N)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.in_ptr = torch.empty(N + 1, **i32)
+        self.out_ptr = torch.empty(N + 1, **i32)
+        self.in_src = torch.empty(max(n, 1), **i32)
+        self.in_eid = torch.empty(max(n, 1), **i32)
+        self.out_dst = torch.empty(max(n, 1), **i32)
+        self.out_eid = torch.empty(max(n, 1), **i32)
+        self.loop_eid = torch.empty(max(N, 1), **i32)
+        nws = L.sgs_graph_build_workspace_bytes(n, N)
+        ws = workspace(nws, dev)
+        _lib.check(L.sgs_graph_build(_ptr(ei), n, N, _ptr(self.in_ptr), _ptr(self.in_src), _ptr(self.in_eid),
+                                     _ptr(self.out_ptr), _ptr(self.out_dst), _ptr(self.out_eid), _ptr(self.loop_eid),
+                                     ws.data_ptr(), ws.numel(), _stream()), "sgs_graph_build")
+
+
+def get_graph(edge_index: torch.Tensor, N: int) -> Graph:
+    """Graph for `edge_index`, cached ON the tensor object (dies with it; keyed by its version
+    counter), so the encoder and the GNN that receive the same tensor share one build."""
+    g = getattr(edge_index, "_sgs_graph", None)
+    if g is None or g.N != N or getattr(edge_index, "_sgs_graph_version", -1) != edge_index._version:
+        g = Graph(edge_index, N)
+        try:
+            edge_index._sgs_graph = g
+            edge_index._sgs_graph_version = edge_index._version
+        except Exception:
+            pass
+    return g
+
+
+class Norm:
+    """gcn_norm result for (graph, w): dis, loopw and the normalised weights in both CSR orders.
+    `handle` is the autograd edge through which the layers' gradients wrt the normalised
+    weights ([n_edges] edge order + [N] loops) flow back to `w`; its storage is never read."""
+    __slots__ = ("graph", "w", "dis", "loopw", "what_in", "what_out", "what_loop", "handle")
+
+
+def _norm_forward(graph: Graph, w):
+    L = _lib.lib()
+    dev = graph.edge_index.device
+    nm = Norm()
+    nm.graph, nm.w = graph, w
+    f32 = dict(dtype=torch.float32, device=dev)
+    nm.dis = torch.empty(graph.N, **f32)
+    nm.loopw = torch.empty(graph.N, **f32)
+    nm.what_in = torch.empty(max(graph.n_edges, 1), **f32)
+    nm.what_out = torch.empty(max(graph.n_edges, 1), **f32)
+    nm.what_loop = torch.empty(graph.N, **f32)
+    nm.handle = None
+    _lib.check(L.sgs_gcn_norm_fwd(_ptr(w, torch.float32), graph.n_edges, graph.N, _ptr(graph.in_ptr), _ptr(graph.in_src),
+                                  _ptr(graph.in_eid), _ptr(graph.out_ptr), _ptr(graph.out_dst), _ptr(graph.out_eid),
+                                  _ptr(graph.loop_eid), _ptr(nm.dis), _ptr(nm.loopw), _ptr(nm.what_in), _ptr(nm.what_out),
+                                  _ptr(nm.what_loop), _stream()), "sgs_gcn_norm_fwd")
+    return nm
+
+
+class _GCNNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, graph, box):
+        nm = _norm_forward(graph, w)
+        box.append(nm)
+        ctx.nm = nm
+        return torch.empty(graph.n_edges + graph.N, dtype=torch.float32, device=w.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        nm, gr = ctx.nm, ctx.nm.graph
+        g = g.contiguous()
+        dw = torch.empty(gr.n_edges, dtype=torch.float32, device=g.device)
+        if gr.n_edges > 0:
+            gw, gl = g[:gr.n_edges], g[gr.n_edges:]
+            nws = L.sgs_gcn_norm_bwd_workspace_bytes(gr.N)
+            ws = workspace(nws, g.device)
+            _lib.check(L.sgs_gcn_norm_bwd(_ptr(nm.w), gw.data_ptr(), gl.data_ptr(), gr.n_edges, gr.N, _ptr(nm.dis),
+                                          _ptr(nm.loopw), _ptr(gr.in_ptr), _ptr(gr.in_src), _ptr(gr.in_eid),
+                                          _ptr(gr.out_ptr), _ptr(gr.out_dst), _ptr(gr.out_eid), _ptr(gr.loop_eid),
+                                          _ptr(gr.edge_index), _ptr(dw), ws.data_ptr(), ws.numel(), _stream()),
+                       "sgs_gcn_norm_bwd")
+        return dw, None, None
+
+
+def gcn_norm(graph: Graph, w=None) -> Norm:
+    """K4.  `w` [n_edges] f32 or None (unit weights)."""
+    if w is None:
+        return _norm_forward(graph, None)
+    _need_gpu(w)
+    w = w.contiguous()
+    if w.dtype != torch.float32 or w.numel() != graph.n_edges:
+        raise RuntimeError(f"edge_weight must be float32 [{graph.n_edges}]")
+    if not (w.requires_grad and torch.is_grad_enabled()):
+        return _norm_forward(graph, w.detach())
+    box = []
+    handle = _GCNNorm.apply(w, graph, box)
+    nm = box[0]
+    nm.handle = handle
+    return nm
+
+
+def _spmm(X, ptr, col, val, diag, bias, act, p, seed, site, N, D):
+    L = _lib.lib()
+    Y = torch.empty(N, D, dtype=torch.float32, device=X.device)
+    _lib.check(L.sgs_spmm_csr(_ptr(X, torch.float32), N, D, _ptr(ptr), _ptr(col), _ptr(val), _ptr(diag), _ptr(bias),
+                              act, float(p), seed, site, _ptr(Y), _stream()), "sgs_spmm_csr")
+    return Y
+
+
+class _Propagate(torch.autograd.Function):
+    """Y = act(A_hat X + bias); A_hat from `nm` (K5 forward + its three backward products)."""
+
+    @staticmethod
+    def forward(ctx, X, handle, bias, nm, act, p, seed, site):
+        gr = nm.graph
+        N, D = X.shape
+        Y = _spmm(X, gr.in_ptr, gr.in_src, nm.what_in, nm.what_loop, bias, act, p, seed, site, N, D)
+        ctx.nm, ctx.act, ctx.p = nm, act, p
+        ctx.has_bias, ctx.has_handle = bias is not None, handle is not None
+        ctx.save_for_backward(X, Y if act != ACT_NONE else None)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        L = _lib.lib()
+        nm, gr = ctx.nm, ctx.nm.graph
+        X, Y = ctx.saved_tensors
+        N, D = X.shape
+        dY = dY.contiguous()
+        if ctx.act != ACT_NONE:
+            dZ = torch.empty_like(dY)
+            _lib.check(L.sgs_act_bwd(_ptr(dY), _ptr(Y), dY.numel(), ctx.act, float(ctx.p), _ptr(dZ), _stream()), "sgs_act_bwd")
+        else:
+            dZ = dY
+        dX = dbias = g = None
+        if ctx.needs_input_grad[0]:
+            dX = _spmm(dZ, gr.out_ptr, gr.out_dst, nm.what_out, nm.what_loop, None, ACT_NONE, 0.0, 0, 0, N, D)
+        if ctx.has_handle and ctx.needs_input_grad[1]:
+            g = torch.empty(gr.n_edges + gr.N, dtype=torch.float32, device=dY.device)
+            gw, gl = g[:gr.n_edges], g[gr.n_edges:]
+            _lib.check(L.sgs_sddmm_csr(_ptr(dZ), _ptr(X), N, D, _ptr(gr.in_ptr), _ptr(gr.in_src), _ptr(gr.in_eid),
+                                       gw.data_ptr(), gl.data_ptr(), _stream()), "sgs_sddmm_csr")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dbias = torch.empty(D, dtype=torch.float32, device=dY.device)
+            _lib.check(L.sgs_colsum(_ptr(dZ), N, D, _ptr(dbias), _stream()), "sgs_colsum")
+        return dX, g, dbias, None, None, None, None, None
+
+
+def gcn_propagate(X, nm: Norm, bias=None, act=ACT_NONE, p=0.0, seed=0, site=0):
+    """K5: act(A_hat X + bias) with autograd to X, bias and (through nm.handle) the edge weights."""
+    _need_gpu(X, bias)
+    if X.dtype != torch.float32 or X.dim() != 2 or X.shape[0] != nm.graph.N:
+        raise RuntimeError("gcn_propagate: X must be float32 [N, D]")
+    return _Propagate.apply(X.contiguous(), nm.handle, bias, nm, act, float(p), int(seed), int(site))
+
+
+# ------------------------------------------------------------------ edge scorer (K1b)
+class ActiveSet:
+    """Which edges can carry a non-zero upstream gradient into the scorer's backward.
+    None = all (dense backward over every scored edge).  The hybrid pipeline sets it to the
+    q sampled edges after the draw (every other entry of dL/dp is exactly zero there,
+    training_hybrid.py:86), which cuts the scorer's backward from E to q rows."""
+    __slots__ = ("eid", "graph")
+
+    def __init__(self):
+        self.eid, self.graph = None, None
+
+    def set(self, eid: torch.Tensor, graph: Graph):
+        self.eid, self.graph = eid, graph
+
+
+def _colsum(A):
+    L = _lib.lib()
+    out = torch.empty(A.shape[1], dtype=torch.float32, device=A.device)
+    _lib.check(L.sgs_colsum(_ptr(A), A.shape[0], A.shape[1], _ptr(out), _stream()), "sgs_colsum")
+    return out
+
+
+def _endpoint_reduce(M_out, M_in, T, graph: Graph, s_out, s_in, H):
+    L = _lib.lib()
+    out = torch.empty(graph.N, H, dtype=torch.float32, device=M_out.device)
+    _lib.check(L.sgs_endpoint_reduce(_ptr(M_out), _ptr(M_in), _ptr(T), graph.N, H, _ptr(graph.in_ptr), _ptr(graph.in_src), _ptr(graph.in_eid),
+                                     _ptr(graph.out_ptr), _ptr(graph.out_dst), _ptr(graph.out_eid), float(s_out), float(s_in),
+                                     _ptr(out), _stream()), "sgs_endpoint_reduce")
+    return out
+
+
+class _EdgeScore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, codes, U, W1, b1, w2, b2, edge_index, active, p, seed, site):
+        L = _lib.lib()
+        N, H = codes.shape
+        E = edge_index.shape[1]
+        out = torch.empty(E, dtype=torch.float32, device=codes.device)
+        ws = workspace(L.sgs_edge_score_workspace_bytes(H), codes.device)
+        _lib.check(L.sgs_edge_score_fwd(_ptr(codes, torch.float32), _ptr(U, torch.float32), N, H, _ptr(edge_index, torch.int64), E,
+                                        _ptr(W1, torch.float32), _ptr(b1), _ptr(w2), _ptr(b2), float(p), seed, site, _ptr(out),
+                                        ws.data_ptr(), ws.numel(), _stream()), "sgs_edge_score_fwd")
+        ctx.save_for_backward(codes, U, W1, b1, w2, b2, edge_index)
+        ctx.active, ctx.p, ctx.seed, ctx.site = active, float(p), seed, site
+        return out
+
+    @staticmethod
+    def backward(ctx, gp):
+        L = _lib.lib()
+        codes, U, W1, b1, w2, b2, edge_index = ctx.saved_tensors
+        N, H = codes.shape
+        E = edge_index.shape[1]
+        dev = codes.device
+        act = ctx.active
+        if act is not None and act.eid is not None:
+            eid, graph = act.eid, act.graph
+            n = eid.numel()
+            gp_act = gp.index_select(0, eid)
+        else:
+            eid, graph, n = None, get_graph(edge_index, N), E
+            gp_act = gp.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        dv, hdz, feat = torch.empty(n, H, **f32), torch.empty(n, H, **f32), torch.empty(n, H, **f32)
+        dz = torch.empty(n, **f32)
+        if n > 0:
+            ws = workspace(L.sgs_edge_score_workspace_bytes(H), dev)
+            _lib.check(L.sgs_edge_score_bwd_core(_ptr(codes), _ptr(U), N, H, _ptr(edge_index), E, _ptr(eid), n, _ptr(gp_act),
+                                                 _ptr(W1), _ptr(b1), _ptr(w2), _ptr(b2), ctx.p, ctx.seed, ctx.site, _ptr(dv),
+                                                 _ptr(hdz), _ptr(dz), _ptr(feat), ws.data_ptr(), ws.numel(), _stream()),
+                       "sgs_edge_score_bwd_core")
+        W1a = W1[:, :H]
+        dfeat = dv @ W1a                                   # [n,H]   library GEMM
+        dW1 = torch.zeros_like(W1)
+        dW1[:, :H] = dv.t() @ feat                         # [H,H]   library GEMM (W1b's half arrives through U)
+        db1, dw2 = _colsum(dv), _colsum(hdz)
+        db2 = dz.sum().reshape(1)
+        dcodes = _endpoint_reduce(dfeat, dfeat, codes, graph, 1.0, 1.0, H)
+        dU = _endpoint_reduce(dv, dv, None, graph, 1.0, -1.0, H)
+        return dcodes, dU, dW1, db1, dw2, db2, None, None, None, None, None
+
+
+def edge_score(codes, fc1_w, fc1_b, fc2_w, fc2_b, edge_index, active=None, p=0.0, seed=0, site=0):
+    """K1b.  codes [N,H]; fc1_w [H,2H]; fc1_b [H]; fc2_w [1,H]; fc2_b [1]; edge_index [2,E] -> p [E]."""
+    _need_gpu(codes, fc1_w, edge_index)
+    H = codes.shape[1]
+    U = codes @ fc1_w[:, H:].t()                           # node-level half of fc1 (library GEMM)
+    return _EdgeScore.apply(codes.contiguous(), U.contiguous(), fc1_w.contiguous(), fc1_b.contiguous(),
+                            fc2_w.reshape(-1).contiguous(), fc2_b.contiguous(), edge_index.contiguous(), active, float(p),
+                            int(seed), int(site))

@@ -1,0 +1,92 @@
+"""Edge scorers: mirror of model.py:8-145 (EdgeProbMLP, EdgeProbGCN, get_edge_mlp)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .model import GCNConv, _DropoutClock, SITE_ENC, SITE_SCORE, SITE_MLP_X, SITE_MLP_Y
+
+
+class EdgeProbGCN(nn.Module):
+    """model.py:91-133: 2-layer GCN encoder over `random_sampled_edge_index` (or `edge_index`
+    when None), then `_edge_score` for EVERY column of `edge_index`."""
+
+    def __init__(self, in_channels, hidden_dim, dropout_prob=0.2):
+        super().__init__()
+        self.gcn1 = GCNConv(in_channels, hidden_dim)
+        self.gcn2 = GCNConv(hidden_dim, hidden_dim)
+        self.fc1 = nn.Linear(2 * hidden_dim, hidden_dim)
+        self.dropout = nn.Dropout(dropout_prob)
+        self.fc2 = nn.Linear(hidden_dim, 1)
+        self.last_active = None
+
+    def forward(self, node_features, edge_index, random_sampled_edge_index=None, use_checkpoint=False):
+        # use_checkpoint (model.py:126-129) is accepted and moot: the fused scorer never stores
+        # the [E,2H]/[E,H] activations and always recomputes them in backward.
+        g = random_sampled_edge_index if random_sampled_edge_index is not None else edge_index
+        N = node_features.shape[0]
+        norm = ops.gcn_norm(ops.get_graph(g, N), None)
+        p = self.dropout.p if self.training else 0.0
+        act = ops.ACT_RELU_DROPOUT if p > 0 else ops.ACT_RELU
+        out = self.gcn1(node_features, g, norm=norm, act=act, p=p, seed=_DropoutClock.next_seed(), site=SITE_ENC)
+        out = self.gcn2(out, g, norm=norm, act=ops.ACT_RELU)
+        self.last_active = ops.ActiveSet()
+        prob = ops.edge_score(out, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, edge_index,
+                              active=self.last_active, p=p, seed=_DropoutClock.next_seed(), site=SITE_SCORE)
+        return prob.unsqueeze(1)
+
+
+class EdgeProbMLP(nn.Module):
+    """model.py:8-45: x = drop(relu(fcdim(X[src]))), y = ...(X[dst]) on the columns of
+    `random_sampled_edge_index` (or `edge_index`), then `_edge_score(x, y)`.  The reference
+    applies fcdim to the GATHERED [E',F] rows; relu(fcdim(.)) is row-wise, so it is hoisted to
+    the N nodes (identical values); only the per-(edge, endpoint) dropout has to stay per edge."""
+
+    def __init__(self, in_channels, hidden_dim, dropout_prob=0.2):
+        super().__init__()
+        self.dropout = nn.Dropout(dropout_prob)
+        self.fcdim = nn.Linear(in_channels, hidden_dim)
+        self.fc1 = nn.Linear(2 * hidden_dim, hidden_dim)
+        self.fc2 = nn.Linear(hidden_dim, 1)
+        self.last_active = None
+
+    def forward(self, node_features, edge_index, random_sampled_edge_index=None, use_checkpoint=False):
+        g = random_sampled_edge_index if random_sampled_edge_index is not None else edge_index
+        A = F.relu(self.fcdim(node_features))
+        p = self.dropout.p if self.training else 0.0
+        self.last_active = ops.ActiveSet()
+        if p == 0.0:
+            prob = ops.edge_score(A, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, g,
+                                  active=self.last_active)
+        else:
+            Eg, H = g.shape[1], A.shape[1]
+            sx, sy, ss = _DropoutClock.next_seed(), _DropoutClock.next_seed(), _DropoutClock.next_seed()
+            kx = ops.dropout_keep(sx, SITE_MLP_X, Eg, H, p, A.device)
+            ky = ops.dropout_keep(sy, SITE_MLP_Y, Eg, H, p, A.device)
+            table = torch.cat([A[g[0]] * kx / (1 - p), A[g[1]] * ky / (1 - p)], dim=0)      # [2E',H] endpoint codes
+            ar = torch.arange(Eg, device=A.device)
+            pair = torch.stack([ar, ar + Eg])
+            prob = ops.edge_score(table, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, pair,
+                                  active=self.last_active, p=p, seed=ss, site=SITE_SCORE)
+        return prob.unsqueeze(1)
+
+
+class EdgeProbSAGE(nn.Module):
+    """model.py:47-89 (`--edge_mlp_type GSAGE`): outside the round-1 scope."""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+        raise NotImplementedError("EdgeProbSAGE (GSAGE scorer) is not part of the MI355X hot path yet")
+
+
+def get_edge_mlp(in_channels, hidden_dim, dropout_prob, edge_mlp_type='MLP'):
+    """model.py:135-145."""
+    if edge_mlp_type == 'MLP':
+        return EdgeProbMLP(in_channels, hidden_dim, dropout_prob)
+    if edge_mlp_type == 'GSAGE':
+        return EdgeProbSAGE(in_channels, hidden_dim, dropout_prob)
+    if edge_mlp_type == 'GCN':
+        return EdgeProbGCN(in_channels, hidden_dim, dropout_prob)
+    raise NotImplementedError

@@ -1,0 +1,89 @@
+"""GPU parity: fused MFMA edge scorer (K1b) forward / backward vs the oracle's `_edge_score`."""
+import pytest
+import torch
+
+from oracle import sgs_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import sgs_gnn_amd
+    return sgs_gnn_amd.ops
+
+
+def _case(N, H, E, seed):
+    g = torch.Generator().manual_seed(seed)
+    codes = torch.relu(torch.randn(N, H, generator=g))          # encoder output is post-ReLU
+    ei = torch.randint(0, N, (2, E), generator=g)
+    if E > 5:
+        ei[:, 2] = ei[0, 2]                                       # a self loop among the scored edges
+    b = 1.0 / (2 * H) ** 0.5
+    W1 = (torch.rand(H, 2 * H, generator=g) * 2 - 1) * b
+    b1 = (torch.rand(H, generator=g) * 2 - 1) * b
+    W2 = (torch.rand(1, H, generator=g) * 2 - 1) / H ** 0.5
+    b2 = (torch.rand(1, generator=g) * 2 - 1) / H ** 0.5
+    return codes, ei, W1, b1, W2, b2, g
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b.double()).abs().max()) / (float(b.double().abs().max()) + 1e-30)
+
+
+@pytest.mark.parametrize("N,H,E", [(50, 16, 300), (50, 32, 129), (300, 64, 5000), (200, 128, 1000), (1013, 256, 20000), (7, 8, 1),
+                                   (40, 48, 500)])
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_forward_and_dense_backward(ops, N, H, E, p):
+    codes, ei, W1, b1, W2, b2, g = _case(N, H, E, N + H + E)
+    seed, site = 4242, 2
+    keep = ops.dropout_keep(seed, site, E, H, p, DEV).cpu() if p > 0 else None
+    gp = torch.randn(E, generator=g)
+
+    leaves = [t.clone().double().requires_grad_(True) for t in (codes, W1, b1, W2, b2)]
+    co, W1o, b1o, W2o, b2o = leaves
+    po = O.edge_score(co[ei[0]], co[ei[1]], W1o, b1o, W2o, b2o, p, keep).squeeze(1)
+    po.backward(gp.double())
+
+    dl = [t.clone().to(DEV).requires_grad_(True) for t in (codes, W1, b1, W2, b2)]
+    cd, W1d, b1d, W2d, b2d = dl
+    pd = ops.edge_score(cd, W1d, b1d, W2d, b2d, ei.to(DEV), active=None, p=p, seed=seed, site=site)
+    assert float((pd.detach().cpu().double() - po.detach()).abs().max()) < 2e-6          # probabilities
+    pd.backward(gp.to(DEV))
+    for name, a, b in zip(["dcodes", "dW1", "db1", "dW2", "db2"], dl, leaves):
+        if name == "db2":     # a single signed sum of E terms: bound the error by the terms' magnitude, not the (cancelled) sum
+            assert abs(float(a.grad) - float(b.grad)) < 2e-6 * float(gp.abs().sum()) / 4, name
+        else:
+            assert _rel(a.grad, b.grad) < 2e-5, name
+
+
+def test_active_subset_backward_equals_dense_with_masked_gradient(ops):
+    """Hybrid pipeline: only the q sampled edges carry gradient (training_hybrid.py:86)."""
+    N, H, E, q = 400, 64, 6000, 1200
+    codes, ei, W1, b1, W2, b2, g = _case(N, H, E, 9)
+    eid = torch.sort(torch.randperm(E, generator=g)[:q]).values
+    gq = torch.randn(q, generator=g)
+    gp = torch.zeros(E)
+    gp[eid] = gq
+    res = []
+    for use_active in (False, True):
+        dl = [t.clone().to(DEV).requires_grad_(True) for t in (codes, W1, b1, W2, b2)]
+        act = ops.ActiveSet()
+        pd = ops.edge_score(dl[0], dl[1], dl[2], dl[3], dl[4], ei.to(DEV), active=act)
+        if use_active:
+            sei = ei[:, eid].to(DEV)
+            act.set(eid.to(DEV), ops.Graph(sei, N))
+        pd.backward(gp.to(DEV))
+        res.append([t.grad.cpu() for t in dl])
+    for a, b in zip(*res):
+        assert _rel(a, b) < 1e-5
+
+
+def test_scorer_tail_and_probability_range(ops):
+    N, H, E = 1013, 256, 100001          # E not a multiple of the 128-edge tile
+    codes, ei, W1, b1, W2, b2, _ = _case(N, H, E, 3)
+    pd = ops.edge_score(codes.to(DEV), W1.to(DEV), b1.to(DEV), W2.to(DEV), b2.to(DEV), ei.to(DEV))
+    po = O.edge_score(codes[ei[0]], codes[ei[1]], W1, b1, W2, b2).squeeze(1)
+    assert pd.shape == (E,) and float(pd.min()) > 0 and float(pd.max()) < 1
+    assert float((pd.cpu() - po).abs().max()) < 2e-6

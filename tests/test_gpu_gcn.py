@@ -1,0 +1,144 @@
+"""GPU parity: graph build, gcn_norm, CSR SpMM / SDDMM and their autograd glue vs the oracle."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sgs_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import sgs_gnn_amd
+    return sgs_gnn_amd
+
+
+def rand_graph(N, E, seed, loops=True):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    if loops and E > 12:
+        ei[:, 3] = ei[0, 3]
+        ei[:, 7] = ei[0, 3]      # a second self loop on the same node: the last one wins
+        ei[:, 11] = ei[0, 11]
+    return ei, g
+
+
+@pytest.mark.parametrize("N,E", [(1, 0), (5, 3), (50, 700), (1013, 100000), (3, 30000), (40000, 90000)])
+def test_graph_build_matches_stable_sort(pkg, N, E):
+    ei, _ = rand_graph(N, E, N + E)
+    gr = pkg.ops.Graph(ei.to(DEV), N)
+    torch.cuda.synchronize()
+    src, dst = ei[0], ei[1]
+    for ptr, col, eid, key, other in [(gr.in_ptr, gr.in_src, gr.in_eid, dst, src), (gr.out_ptr, gr.out_dst, gr.out_eid, src, dst)]:
+        want_ptr = torch.zeros(N + 1, dtype=torch.int64)
+        want_ptr[1:] = torch.cumsum(torch.bincount(key, minlength=N), 0)
+        assert torch.equal(ptr.cpu().long(), want_ptr)
+        order = torch.sort(key, stable=True).indices
+        assert torch.equal(eid.cpu().long()[:E], order)
+        assert torch.equal(col.cpu().long()[:E], other[order])
+    want_loop = torch.full((N,), -1, dtype=torch.int64)
+    for e in range(E):
+        if src[e] == dst[e]:
+            want_loop[src[e]] = e
+    assert torch.equal(gr.loop_eid.cpu().long()[:N], want_loop)
+
+
+@pytest.mark.parametrize("N,E,Fin,D", [(40, 300, 9, 16), (40, 300, 9, 41), (200, 5000, 33, 256), (64, 900, 5, 7), (30, 200, 4, 70),
+                                       (17, 60, 3, 512), (25, 0, 3, 8)])
+@pytest.mark.parametrize("weighted", [True, False])
+def test_gcn_conv_forward_backward_vs_oracle(pkg, N, E, Fin, D, weighted):
+    from sgs_gnn_amd.model import GCNConv
+    ei, g = rand_graph(N, E, N * 3 + D)
+    x = torch.randn(N, Fin, generator=g)
+    w = torch.rand(E, generator=g) if weighted else None
+    conv = GCNConv(Fin, D)
+    with torch.no_grad():
+        conv.bias.uniform_(-0.5, 0.5)
+    W, b = conv.lin.weight.detach().clone(), conv.bias.detach().clone()
+    gy = torch.randn(N, D, generator=g)
+
+    # oracle (fp32 and fp64)
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        xo = x.clone().to(dt).requires_grad_(True)
+        Wo, bo = W.clone().to(dt).requires_grad_(True), b.clone().to(dt).requires_grad_(True)
+        wo = w.clone().to(dt).requires_grad_(True) if weighted else None
+        yo = O.gcn_conv(xo, ei, wo, Wo, bo)
+        yo.backward(gy.to(dt))
+        res[dt] = (yo.detach(), xo.grad, Wo.grad, bo.grad, wo.grad if weighted else None)
+
+    conv = conv.to(DEV)
+    xd = x.clone().to(DEV).requires_grad_(True)
+    wd = w.clone().to(DEV).requires_grad_(True) if weighted else None
+    yd = conv(xd, ei.to(DEV), wd)
+    yd.backward(gy.to(DEV))
+    got = (yd.detach().cpu(), xd.grad.cpu(), conv.lin.weight.grad.cpu(), conv.bias.grad.cpu(), wd.grad.cpu() if weighted else None)
+    for name, a, r32, r64 in zip(["y", "dx", "dW", "db", "dw"], got, res[torch.float32], res[torch.float64]):
+        if a is None or a.numel() == 0:
+            continue
+        # error vs fp64 truth no worse than a few times the fp32 oracle's own error, and <= 1e-4
+        scale = float(r64.abs().max()) + 1e-12
+        err = float((a.double() - r64).abs().max()) / scale
+        err32 = float((r32.double() - r64).abs().max()) / scale
+        assert err <= max(5 * err32, 2e-6) and err < 1e-4, f"{name}: rel err {err:.2e} (fp32 oracle {err32:.2e})"
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_gnn_model_two_layers_vs_oracle(pkg, p):
+    """GNNModel.forward (model.py:155-164): shared norm across layers, fused ReLU+dropout, edge-weight
+    gradient through both layers and through the degree normalisation."""
+    from sgs_gnn_amd import model as M
+    N, E, Fin, H, C = 120, 2000, 20, 32, 6
+    ei, g = rand_graph(N, E, 77)
+    x = torch.randn(N, Fin, generator=g)
+    w = torch.rand(E, generator=g)
+    P = O.init_params(Fin, H, C, "GCN", seed=5)
+
+    class D_:
+        pass
+    data = D_()
+    data.x = x.to(DEV)
+    m = M.GNNModel.__new__(M.GNNModel)
+    torch.nn.Module.__init__(m)
+    m.gcn1, m.gcn2, m.dropout = M.GCNConv(Fin, H), M.GCNConv(H, C), torch.nn.Dropout(p)
+    with torch.no_grad():
+        m.gcn1.lin.weight.copy_(P["gcn1.lin.weight"]); m.gcn1.bias.copy_(P["gcn1.bias"])
+        m.gcn2.lin.weight.copy_(P["gcn2.lin.weight"]); m.gcn2.bias.copy_(P["gcn2.bias"])
+    m = m.to(DEV).train()
+    M.set_dropout_seed(99)
+    seed = (M._DropoutClock.base * 0x9E3779B97F4A7C15 + 1 * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    keep = pkg.ops.dropout_keep(seed, M.SITE_GNN, N, H, p, DEV).cpu() if p > 0 else None
+    if p > 0:
+        assert abs(float(keep.float().mean()) - (1 - p)) < 0.03
+    wd = w.to(DEV).requires_grad_(True)
+    out = m(data, ei.to(DEV), wd)
+    gy = torch.randn(N, C, generator=g)
+    out.backward(gy.to(DEV))
+
+    Po = {k: v.clone().double().requires_grad_(True) for k, v in P.items()}
+    wo = w.double().requires_grad_(True)
+    oo = O.gnn_forward(Po, x.double(), ei, wo, p, keep)
+    oo.backward(gy.double())
+    def rel(a, b):
+        return float((a.double().cpu() - b).abs().max()) / (float(b.abs().max()) + 1e-12)
+    assert rel(out.detach(), oo.detach()) < 1e-5
+    assert rel(wd.grad, wo.grad) < 1e-4
+    assert rel(m.gcn1.lin.weight.grad, Po["gcn1.lin.weight"].grad) < 1e-4
+    assert rel(m.gcn1.bias.grad, Po["gcn1.bias"].grad) < 1e-4
+    assert rel(m.gcn2.lin.weight.grad, Po["gcn2.lin.weight"].grad) < 1e-4
+    assert rel(m.gcn2.bias.grad, Po["gcn2.bias"].grad) < 1e-4
+
+
+def test_propagate_is_run_to_run_deterministic(pkg):
+    N, E, D = 1013, 100000, 256
+    ei, g = rand_graph(N, E, 5)
+    X = torch.randn(N, D, generator=g).to(DEV)
+    w = torch.rand(E, generator=g).to(DEV)
+    outs = []
+    for _ in range(3):
+        gr = pkg.ops.Graph(ei.to(DEV), N)
+        nm = pkg.ops.gcn_norm(gr, w)
+        outs.append(pkg.ops.gcn_propagate(X, nm))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
