@@ -1,6 +1,11 @@
 """sgs_gnn_amd -- MI355X (gfx950) native hot path of SGS-GNN behind the reference's own
 Python interface.  The numeric work lives in libsgs_hip.so (csrc/*.hip, C ABI in
-include/sgs_hip.h); this package is the host-side mirror of the reference's call sites."""
+include/sgs_hip.h); this package is the host-side mirror of the reference's call sites
+(model.py, sampling.py, training*.py, utils.py).  No CPU fallback exists."""
 from . import _lib, ops  # noqa: F401
-
-__all__ = ["_lib", "ops"]
+from .model import GCNConv, GNNModel, set_dropout_seed  # noqa: F401
+from .scorer import EdgeProbGCN, EdgeProbMLP, EdgeProbSAGE, get_edge_mlp  # noqa: F401
+from .sampling import gumbel_softmax_sampling, random_edge_sampling, manual_seed  # noqa: F401
+from .training import train, train_hybrid, train_straight_through, train_two_pass  # noqa: F401
+from .utils import calculate_f1, consistency_loss, fix_seeds  # noqa: F401
+from .data import Batch, degree_prior, synthetic_graph, reddit_partition_stream  # noqa: F401

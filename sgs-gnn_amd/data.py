@@ -1,0 +1,85 @@
+"""Batch duck-type of the reference's loaders (PyG `Data` as ClusterLoader yields it: .x, .edge_index,
+.y, .train_mask/.val_mask/.test_mask, .prob, .to(device)) and seeded synthetic look-alikes of the
+benchmark graphs: real datasets cannot be fetched offline."""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+class Batch:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    @property
+    def num_nodes(self):
+        return self.x.shape[0]
+
+    def to(self, device):
+        dev = torch.device(device)
+        if self.x.device == dev or (dev.type == "cuda" and self.x.is_cuda and dev.index in (None, self.x.device.index)):
+            return self
+        out = Batch(**{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in self.__dict__.items() if not k.startswith("_sgs")})
+        return out
+
+
+def degree_prior(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """`data.prob` of datasets.py:141-156 (add_degree) for a row-sorted edge_index:
+    softmax_e( E^-1/2 / (colcount[row_e] + rowcount[col_e] + 1e-10) )."""
+    row, col = edge_index[0], edge_index[1]
+    E = edge_index.shape[1]
+    rowcount = torch.bincount(row, minlength=num_nodes).to(torch.float32)
+    colcount = torch.bincount(col, minlength=num_nodes).to(torch.float32)
+    prob = 1.0 / ((colcount[row] + rowcount[col]) + 1e-10)
+    return F.softmax(prob * E ** -0.5, dim=0)
+
+
+def synthetic_graph(n: int, n_edges_target: int, nfeat: int, ncls: int, seed: int, train_frac: float = 0.66,
+                    power: float = 0.8, device="cpu") -> Batch:
+    """Undirected, loop-free, coalesced, row-sorted degree-corrected random graph with power-law
+    expected degrees (both directions stored), N(0,1) features with a weak class signal, uniform
+    labels, Bernoulli masks and the reference's degree prior."""
+    g = torch.Generator().manual_seed(seed)
+    wts = (torch.arange(1, n + 1, dtype=torch.float64) ** (-power))
+    wts = wts[torch.randperm(n, generator=g)]
+    m = n_edges_target // 2
+    max_pairs = n * (n - 1) // 2
+    m = min(m, int(max_pairs * 0.9))
+    keys = torch.zeros(0, dtype=torch.int64)
+    while keys.numel() < m:                       # draw endpoint pairs ~ w_i w_j, dedupe, repeat
+        need = int((m - keys.numel()) * 1.3) + 16
+        a = torch.multinomial(wts, need, replacement=True, generator=g)
+        b = torch.multinomial(wts, need, replacement=True, generator=g)
+        ok = a != b
+        lo, hi = torch.minimum(a[ok], b[ok]), torch.maximum(a[ok], b[ok])
+        keys = torch.unique(torch.cat([keys, lo * n + hi]))
+    keys = keys[torch.randperm(keys.numel(), generator=g)[:m]]
+    lo, hi = keys // n, keys % n
+    both = torch.unique(torch.cat([lo * n + hi, hi * n + lo]))       # sorted -> row-sorted, coalesced
+    ei = torch.stack([both // n, both % n])
+    y = torch.randint(0, ncls, (n,), generator=g)
+    x = torch.randn(n, nfeat, generator=g)
+    x[torch.arange(n), y % nfeat] += 1.5
+    r = torch.rand(n, generator=g)
+    tm = r < train_frac
+    vm = (r >= train_frac) & (r < train_frac + (1 - train_frac) * 0.3)
+    b = Batch(x=x, edge_index=ei, y=y, train_mask=tm, val_mask=vm, test_mask=~(tm | vm), prob=degree_prior(ei, n))
+    return b.to(device) if str(device) != "cpu" else b
+
+
+def reddit_partition_stream(num_parts: int = 230, seed: int = 42, nfeat: int = 602, ncls: int = 41, n: int = 1013,
+                            e_lo: int = 60_000, e_hi: int = 500_000, frac_above_q: float = 0.52, q: int = 100_000,
+                            device="cpu"):
+    """S3 of SURVEY.md section 8d: a Reddit-like METIS partition stream -- `num_parts` batches of
+    ~1013 nodes whose intra-partition edge counts mirror the reference run (119 of 230 partitions
+    exceed q = 100 000; logs/pipeline_hybrid.log:8)."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(num_parts):
+        above = bool(torch.rand(1, generator=g) < frac_above_q)
+        lo, hi = (q + 2_000, e_hi) if above else (e_lo, q - 2_000)
+        E = int(lo + (hi - lo) * float(torch.rand(1, generator=g)))
+        out.append(synthetic_graph(n, E, nfeat, ncls, seed * 1000 + i, device=device))
+    return out

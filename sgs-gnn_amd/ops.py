@@ -383,3 +383,100 @@ def edge_score(codes, fc1_w, fc1_b, fc2_w, fc2_b, edge_index, active=None, p=0.0
     return _EdgeScore.apply(codes.contiguous(), U.contiguous(), fc1_w.contiguous(), fc1_b.contiguous(),
                             fc2_w.reshape(-1).contiguous(), fc2_b.contiguous(), edge_index.contiguous(), active, float(p),
                             int(seed), int(site))
+
+
+# ------------------------------------------------------------------ gate + losses (K6)
+def _u8(mask: torch.Tensor) -> torch.Tensor:
+    if mask.dtype == torch.bool:
+        return mask.contiguous().view(torch.uint8)
+    if mask.dtype == torch.uint8:
+        return mask.contiguous()
+    raise RuntimeError("mask must be a bool tensor")
+
+
+def masked_correct(logits, y, train_mask) -> torch.Tensor:
+    """int32 [2] on device: (#correct argmax on train rows, #train rows) -- no host sync."""
+    L = _lib.lib()
+    _need_gpu(logits, y, train_mask)
+    out = torch.empty(2, dtype=torch.int32, device=logits.device)
+    N, C = logits.shape
+    _lib.check(L.sgs_masked_correct(_ptr(logits.contiguous(), torch.float32), N, C, _ptr(y, torch.int64), _ptr(_u8(train_mask)),
+                                    _ptr(out), _stream()), "sgs_masked_correct")
+    return out
+
+
+class _MaskedCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, y, mask_u8):
+        L = _lib.lib()
+        N, C = logits.shape
+        dev = logits.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        row_lse = torch.empty(N, dtype=torch.float32, device=dev)
+        rowloss = torch.empty(N, dtype=torch.float32, device=dev)
+        n_rows = torch.empty(1, dtype=torch.int32, device=dev)
+        _lib.check(L.sgs_masked_ce_fwd(_ptr(logits), N, C, _ptr(y), _ptr(mask_u8), _ptr(loss), _ptr(row_lse), _ptr(rowloss),
+                                       _ptr(n_rows), _stream()), "sgs_masked_ce_fwd")
+        ctx.save_for_backward(logits, y, mask_u8, row_lse, n_rows)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        logits, y, mask_u8, row_lse, n_rows = ctx.saved_tensors
+        N, C = logits.shape
+        g = g.reshape(1).contiguous().float()
+        d = torch.empty_like(logits)
+        _lib.check(L.sgs_masked_ce_bwd(_ptr(logits), N, C, _ptr(y), _ptr(mask_u8), _ptr(row_lse), _ptr(n_rows), _ptr(g), _ptr(d),
+                                       _stream()), "sgs_masked_ce_bwd")
+        return d, None, None
+
+
+def masked_cross_entropy(logits, y, train_mask):
+    """nn.CrossEntropyLoss()(logits[train_mask], y[train_mask]) without the boolean-index sync."""
+    _need_gpu(logits, y, train_mask)
+    return _MaskedCE.apply(logits.contiguous(), y.contiguous(), _u8(train_mask))
+
+
+class _EdgeReg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, logits, sei, y, mask_u8, graph, coef1, coef2, box):
+        L = _lib.lib()
+        q = w.numel()
+        N, C = logits.shape
+        dev = w.device
+        out = torch.empty(5, dtype=torch.float32, device=dev)
+        ws = workspace(L.sgs_edge_reg_workspace_bytes(q), dev)
+        _lib.check(L.sgs_edge_reg_fwd(_ptr(w), _ptr(sei), q, _ptr(logits), N, C, _ptr(y), _ptr(mask_u8), float(coef1), float(coef2),
+                                      _ptr(out), None, ws.data_ptr(), ws.numel(), _stream()), "sgs_edge_reg_fwd")
+        ctx.save_for_backward(w, logits, sei, y, mask_u8, out)
+        ctx.graph, ctx.coef1, ctx.coef2 = graph, float(coef1), float(coef2)
+        box.append(out)
+        return out[4].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        w, logits, sei, y, mask_u8, out = ctx.saved_tensors
+        q = w.numel()
+        N, C = logits.shape
+        dev = w.device
+        g = g.reshape(1).contiguous().float()
+        dw = torch.empty(q, dtype=torch.float32, device=dev)
+        Gs = torch.empty(q, C, dtype=torch.float32, device=dev)
+        Gd = torch.empty(q, C, dtype=torch.float32, device=dev)
+        _lib.check(L.sgs_edge_reg_bwd(_ptr(w), _ptr(sei), q, _ptr(logits), N, C, _ptr(y), _ptr(mask_u8), _ptr(out), ctx.coef1,
+                                      ctx.coef2, _ptr(g), _ptr(dw), _ptr(Gs), _ptr(Gd), _stream()), "sgs_edge_reg_bwd")
+        dlogits = _endpoint_reduce(Gs, Gd, None, ctx.graph, 1.0, 1.0, C) if ctx.coef2 != 0.0 else None
+        return dw, dlogits, None, None, None, None, None, None, None
+
+
+def edge_regularizers(w, logits, sampled_edge_index, y, train_mask, coef1, coef2):
+    """coef1 * reg1 + coef2 * reg2 (training_hybrid.py:107-133) as one scalar, plus the detached
+    [reg1, reg2, #valid, sum labels, total] vector."""
+    _need_gpu(w, logits, sampled_edge_index, y, train_mask)
+    graph = get_graph(sampled_edge_index, logits.shape[0])
+    box = []
+    total = _EdgeReg.apply(w.contiguous(), logits.contiguous(), sampled_edge_index.contiguous(), y.contiguous(),
+                           _u8(train_mask), graph, float(coef1), float(coef2), box)
+    return total, box[0]
