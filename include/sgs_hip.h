@@ -171,7 +171,8 @@ int sgs_sddmm_csr(const float* A, const float* B, int64_t N, int64_t D, const in
 /* dZ = dY * act'(Y) for the fused epilogue above (Y is the layer OUTPUT: Y > 0 iff kept and
  * positive, so no mask is stored);  colsum: out[d] = sum_i A[i,d]  (bias gradient). */
 int sgs_act_bwd(const float* dY, const float* Y, int64_t n, int act, float p_drop, float* dZ, sgs_stream_t stream);
-int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, sgs_stream_t stream);
+size_t sgs_colsum_workspace_bytes(int64_t N, int64_t D);
+int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, void* ws, size_t ws_bytes, sgs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K1b: fused edge scorer (model.py:29-34 / 115-122 `_edge_score`; never materialises the

@@ -360,14 +360,30 @@ __global__ void __launch_bounds__(kT) act_bwd(const float* __restrict__ dY, cons
     dZ[i] = g;
 }
 
-// Column sums of a [N, D] matrix (bias gradient): one block per 64 columns, fixed row order.
-__global__ void __launch_bounds__(kT) colsum(const float* __restrict__ A, int64_t N, int64_t D, float* __restrict__ out) {
+// Column sums of a [N, D] matrix (bias / fc2 gradients), two fixed-order stages so the result is
+// deterministic and the first stage fills the chip: block (cx, ry) sums kColRows rows of 64 columns.
+constexpr int kColRows = 256;
+__global__ void __launch_bounds__(kT) colsum_partial(const float* __restrict__ A, int64_t N, int64_t D, float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rgrp = threadIdx.x >> 6;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * kColRows;
+    const int64_t r1 = (r0 + kColRows < N) ? r0 + kColRows : N;
+    float acc = 0.f;
+    if (c < D)
+        for (int64_t r = r0 + rgrp; r < r1; r += 4) acc += A[r * D + c];
+    red[rgrp][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rgrp == 0 && c < D)
+        part[static_cast<int64_t>(blockIdx.y) * D + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void __launch_bounds__(kT) colsum_final(const float* __restrict__ part, int64_t nchunk, int64_t D, float* __restrict__ out) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rgrp = threadIdx.x >> 6;
     float acc = 0.f;
     if (c < D)
-        for (int64_t r = rgrp; r < N; r += 4) acc += A[r * D + c];
+        for (int64_t r = rgrp; r < nchunk; r += 4) acc += part[r * D + c];
     red[rgrp][threadIdx.x & 63] = acc;
     __syncthreads();
     if (rgrp == 0 && c < D) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
@@ -538,12 +554,24 @@ int sgs_act_bwd(const float* dY, const float* Y, int64_t n, int act, float p_dro
     return SGS_OK;
 }
 
-int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, sgs_stream_t stream_) {
+size_t sgs_colsum_workspace_bytes(int64_t N, int64_t D) {
+    if (N < 0) N = 0;
+    if (D < 0) D = 0;
+    return carve_bytes(static_cast<size_t>(cdiv(N, kColRows) + 1) * D, 4) + 256;
+}
+
+int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, void* ws, size_t ws_bytes, sgs_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     SGS_REQUIRE(N >= 0 && D >= 0, SGS_EINVAL, "sgs_colsum: bad sizes");
     if (D == 0) return SGS_OK;
-    SGS_REQUIRE(A && out, SGS_EINVAL, "sgs_colsum: null pointer");
-    hipLaunchKernelGGL(colsum, dim3(cdiv(D, 64)), dim3(kT), 0, stream, A, N, D, out);
+    SGS_REQUIRE(out && (N == 0 || A), SGS_EINVAL, "sgs_colsum: null pointer");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_colsum_workspace_bytes(N, D), SGS_EWORKSPACE, "sgs_colsum: workspace too small");
+    Carver cv(ws);
+    const int64_t nchunk = cdiv(N, kColRows);
+    float* part = cv.take<float>(static_cast<size_t>(nchunk + 1) * D);
+    if (nchunk > 0)
+        hipLaunchKernelGGL(colsum_partial, dim3(cdiv(D, 64), nchunk), dim3(kT), 0, stream, A, N, D, part);
+    hipLaunchKernelGGL(colsum_final, dim3(cdiv(D, 64)), dim3(kT), 0, stream, part, nchunk, D, out);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

@@ -41,32 +41,34 @@ def synthetic_graph(n: int, n_edges_target: int, nfeat: int, ncls: int, seed: in
     """Undirected, loop-free, coalesced, row-sorted degree-corrected random graph with power-law
     expected degrees (both directions stored), N(0,1) features with a weak class signal, uniform
     labels, Bernoulli masks and the reference's degree prior."""
-    g = torch.Generator().manual_seed(seed)
-    wts = (torch.arange(1, n + 1, dtype=torch.float64) ** (-power))
-    wts = wts[torch.randperm(n, generator=g)]
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    kw = dict(generator=g, device=dev)
+    wts = (torch.arange(1, n + 1, dtype=torch.float32, device=dev) ** (-power))
+    wts = wts[torch.randperm(n, **kw)]
     m = n_edges_target // 2
     max_pairs = n * (n - 1) // 2
     m = min(m, int(max_pairs * 0.9))
-    keys = torch.zeros(0, dtype=torch.int64)
+    keys = torch.zeros(0, dtype=torch.int64, device=dev)
     while keys.numel() < m:                       # draw endpoint pairs ~ w_i w_j, dedupe, repeat
         need = int((m - keys.numel()) * 1.3) + 16
         a = torch.multinomial(wts, need, replacement=True, generator=g)
         b = torch.multinomial(wts, need, replacement=True, generator=g)
+        a, b = a.to(torch.int64), b.to(torch.int64)
         ok = a != b
         lo, hi = torch.minimum(a[ok], b[ok]), torch.maximum(a[ok], b[ok])
         keys = torch.unique(torch.cat([keys, lo * n + hi]))
-    keys = keys[torch.randperm(keys.numel(), generator=g)[:m]]
+    keys = keys[torch.randperm(keys.numel(), **kw)[:m]]
     lo, hi = keys // n, keys % n
     both = torch.unique(torch.cat([lo * n + hi, hi * n + lo]))       # sorted -> row-sorted, coalesced
     ei = torch.stack([both // n, both % n])
-    y = torch.randint(0, ncls, (n,), generator=g)
-    x = torch.randn(n, nfeat, generator=g)
-    x[torch.arange(n), y % nfeat] += 1.5
-    r = torch.rand(n, generator=g)
+    y = torch.randint(0, ncls, (n,), **kw)
+    x = torch.randn(n, nfeat, **kw)
+    x[torch.arange(n, device=dev), y % nfeat] += 1.5
+    r = torch.rand(n, **kw)
     tm = r < train_frac
     vm = (r >= train_frac) & (r < train_frac + (1 - train_frac) * 0.3)
-    b = Batch(x=x, edge_index=ei, y=y, train_mask=tm, val_mask=vm, test_mask=~(tm | vm), prob=degree_prior(ei, n))
-    return b.to(device) if str(device) != "cpu" else b
+    return Batch(x=x, edge_index=ei, y=y, train_mask=tm, val_mask=vm, test_mask=~(tm | vm), prob=degree_prior(ei, n))
 
 
 def reddit_partition_stream(num_parts: int = 230, seed: int = 42, nfeat: int = 602, ncls: int = 41, n: int = 1013,
@@ -78,8 +80,9 @@ def reddit_partition_stream(num_parts: int = 230, seed: int = 42, nfeat: int = 6
     g = torch.Generator().manual_seed(seed)
     out = []
     for i in range(num_parts):
-        above = bool(torch.rand(1, generator=g) < frac_above_q)
-        lo, hi = (q + 2_000, e_hi) if above else (e_lo, q - 2_000)
+        # deterministic interleave: every prefix of the stream has ~frac_above_q of its partitions above q
+        above = int((i + 1) * frac_above_q) > int(i * frac_above_q)
+        lo, hi = (int(q * 1.02), e_hi) if above else (e_lo, int(q * 0.98))
         E = int(lo + (hi - lo) * float(torch.rand(1, generator=g)))
         out.append(synthetic_graph(n, E, nfeat, ncls, seed * 1000 + i, device=device))
     return out

@@ -281,8 +281,7 @@ class _Propagate(torch.autograd.Function):
             _lib.check(L.sgs_sddmm_csr(_ptr(dZ), _ptr(X), N, D, _ptr(gr.in_ptr), _ptr(gr.in_src), _ptr(gr.in_eid),
                                        gw.data_ptr(), gl.data_ptr(), _stream()), "sgs_sddmm_csr")
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            dbias = torch.empty(D, dtype=torch.float32, device=dY.device)
-            _lib.check(L.sgs_colsum(_ptr(dZ), N, D, _ptr(dbias), _stream()), "sgs_colsum")
+            dbias = _colsum(dZ)
         return dX, g, dbias, None, None, None, None, None
 
 
@@ -311,8 +310,10 @@ class ActiveSet:
 
 def _colsum(A):
     L = _lib.lib()
-    out = torch.empty(A.shape[1], dtype=torch.float32, device=A.device)
-    _lib.check(L.sgs_colsum(_ptr(A), A.shape[0], A.shape[1], _ptr(out), _stream()), "sgs_colsum")
+    N, D = A.shape
+    out = torch.empty(D, dtype=torch.float32, device=A.device)
+    ws = workspace(L.sgs_colsum_workspace_bytes(N, D), A.device)
+    _lib.check(L.sgs_colsum(_ptr(A), N, D, _ptr(out), ws.data_ptr(), ws.numel(), _stream()), "sgs_colsum")
     return out
 
 

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .dist import GradSync, is_parallel
 from .sampling import draw_learned, draw_prior, random_edge_sampling
 
 _PIPELINES = ("two_pass", "straight_through", "hybrid")
@@ -82,6 +83,11 @@ def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edg
     total_update = 0
     noise = getattr(args, "_sgs_noise", None) or {}
     trace = getattr(args, "_sgs_trace", None)
+    sync = None
+    if is_parallel():                       # N > 1: average gradients over ranks once per step (dist.py)
+        sync = getattr(model, "_sgs_gradsync", None)
+        if sync is None:
+            sync = model._sgs_gradsync = GradSync(model.parameters())
 
     for batch in cluster_loader:
         if not _has_train_nodes(batch):
@@ -154,11 +160,15 @@ def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edg
                                                                batch.train_mask, c1, c2)
                         loss = loss + reg
                     loss.backward()
+                    if sync is not None:
+                        sync.sync(True)
                     optimizer_edge_prob.step()
                     optimizer_gnn.step()
                 else:
                     loss = _ce(criterion, random_out, batch)
                     loss.backward()
+                    if sync is not None and sync.sync(False):
+                        optimizer_edge_prob.step()          # another rank's gate chose "learned"
                     optimizer_gnn.step()
 
                 if trace is not None:
@@ -171,6 +181,8 @@ def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edg
                 out = model(batch, batch.edge_index)
                 loss = _ce(criterion, out, batch)
                 loss.backward()
+                if sync is not None and sync.sync(False):
+                    optimizer_edge_prob.step()
                 optimizer_gnn.step()
 
         elif mode == 'random':
