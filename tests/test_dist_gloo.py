@@ -1,0 +1,61 @@
+"""CPU, world_size 2 over gloo: the N > 1 host logic (partition sharding + the flat-bucket gradient
+average with the gate flag).  The HIP compute is not involved here."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from importlib import import_module
+        import sgs_gnn_amd  # noqa: F401
+        D = import_module("sgs_gnn_amd.dist")
+        assert D.is_parallel()
+        assert D.shard_batches(list(range(7)), rank, world) == list(range(7))[rank::world]
+        torch.manual_seed(0)
+        lin = torch.nn.Linear(5, 3)
+        extra = torch.nn.Parameter(torch.zeros(4))          # a parameter with no grad on rank 1
+        params = list(lin.parameters()) + [extra]
+        sync = D.GradSync(params)
+        lin.weight.grad = torch.full((3, 5), float(rank + 1))
+        lin.bias.grad = torch.full((3,), 10.0 * (rank + 1))
+        if rank == 0:
+            extra.grad = torch.ones(4)
+        any_learned = sync.sync(learned_flag=(rank == 0))
+        ok = (any_learned is True
+              and torch.allclose(lin.weight.grad, torch.full((3, 5), 1.5))
+              and torch.allclose(lin.bias.grad, torch.full((3,), 15.0))
+              and torch.allclose(extra.grad, torch.full((4,), 0.5)))
+        none_learned = sync.sync(learned_flag=False)
+        q.put((rank, bool(ok), bool(none_learned)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradsync_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True, False), (1, True, False)]
