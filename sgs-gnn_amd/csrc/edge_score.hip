@@ -19,9 +19,9 @@
 namespace sgs {
 namespace {
 
-constexpr int kT = 256;      // 4 waves
-constexpr int kBM = 128;     // edges per workgroup (32 per wave)
-constexpr int kBK = 32;      // k-step
+constexpr int kT = 256;      // 4 waves = 2 edge groups x 2 hidden halves
+constexpr int kBM = 64;      // edges per workgroup (32 per edge group)
+constexpr int kBK = 16;      // k-step
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 // W1 [H][2H] (fc1.weight) -> WaT [k][h] = W1[h][k], k < H
@@ -65,16 +65,25 @@ struct ScoreArgs {
     float* feat;             // backward: [n,H]  x_s * x_d
 };
 
-template <int NT, bool BWD>
-__global__ void __launch_bounds__(kT, 2) edge_score_kernel(ScoreArgs a) {
+// Workgroup = 64 edges x all HP = 32*NT hidden units; wave (eg, hh) owns edges 32eg..32eg+31 and
+// hidden units hh*HP/2 .. (hh+1)*HP/2 - 1, i.e. NT/2 accumulator tiles of 32x32 (<= 64 registers),
+// small enough that three independent workgroups share a CU and hide each other's tile staging,
+// prologue and epilogue behind MFMAs.  EXACT: H == 32*NT (the production H = 256): every bounds
+// check on k / h folds away.
+template <int NT, bool BWD, bool EXACT>
+__global__ void __launch_bounds__(kT, 3) edge_score_kernel(ScoreArgs a) {
     constexpr int HP = 32 * NT;
+    constexpr int NTW = NT / 2;                                   // tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* Wt_s = reinterpret_cast<float*>(smem);                 // [32][HP]
-    float* Ft_s = Wt_s + kBK * HP;                                // [32][128]
-    int* s_idx = reinterpret_cast<int*>(Ft_s + kBK * kBM);        // [128]
-    int* d_idx = s_idx + kBM;                                     // [128]
+    // two LDS stages of {W1a^T tile [kBK][HP], feature tile [kBK][64]}, endpoint ids, fc2 partials
+    float* Wt_s0 = reinterpret_cast<float*>(smem);
+    float* Ft_s0 = Wt_s0 + 2 * kBK * HP;
+    int* s_idx = reinterpret_cast<int*>(Ft_s0 + 2 * kBK * kBM);   // [64]
+    int* d_idx = s_idx + kBM;                                     // [64]
+    float* zpart = reinterpret_cast<float*>(d_idx + kBM);         // [2][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int H = a.H;
+    const int eg = wave & 1, hh = wave >> 1;
+    const int H = EXACT ? HP : a.H;
     const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kBM;
 
     if (tid < kBM) {
@@ -89,70 +98,108 @@ __global__ void __launch_bounds__(kT, 2) edge_score_kernel(ScoreArgs a) {
         d_idx[tid] = d;
     }
 
-    f32x16 acc[NT];
+    f32x16 acc[NTW];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NTW; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const int kh = lane >> 5, l31 = lane & 31;
-    for (int k0 = 0; k0 < H; k0 += kBK) {
-        __syncthreads();   // previous tile fully consumed (also publishes s_idx/d_idx on the first trip)
-        // ---- stage W1a^T[k0:k0+32][0:HP] (zero padded)
-        for (int i = tid; i < kBK * (HP / 4); i += kT) {
+    __syncthreads();   // s_idx / d_idx visible
+
+    // Software pipeline: the NEXT k-step's W rows and endpoint rows are fetched into registers while
+    // the matrix cores work on the current LDS stage; they are multiplied / transposed into the
+    // other stage mid-phase.  One barrier per k-step.
+    constexpr int kWV = (kBK * (HP / 4) + kT - 1) / kT;      // float4 W loads per thread per k-step (<= 4)
+    float4 wreg[kWV], xreg, yreg;
+    const int fe = tid & (kBM - 1), fc = tid >> 6;           // this thread's (edge, float4 chunk) of the feature tile
+    const int my_s = s_idx[fe], my_d = d_idx[fe];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < kWV; ++j) {
+            const int i = j * kT + tid;
             const int k = i / (HP / 4), h4 = (i % (HP / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k0 + k < H && h4 < H) v = *reinterpret_cast<const float4*>(a.WaT + static_cast<int64_t>(k0 + k) * H + h4);
-            *reinterpret_cast<float4*>(Wt_s + k * HP + h4) = v;
+            wreg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (EXACT || (i < kBK * (HP / 4) && k0 + k < H && h4 < H))
+                wreg[j] = *reinterpret_cast<const float4*>(a.WaT + static_cast<int64_t>(k0 + k) * H + h4);
         }
-        // ---- stage the Hadamard feature tile as [k][e]
-#pragma unroll
-        for (int it = 0; it < (kBM * (kBK / 4)) / kT; ++it) {
-            const int id = it * kT + tid;
-            const int e = id & (kBM - 1), c = id >> 7;          // c: float4 chunk 0..7 of the k-step
-            const int kk = k0 + 4 * c;
-            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kk < H) {
-                const float4 x = *reinterpret_cast<const float4*>(a.codes + static_cast<int64_t>(s_idx[e]) * H + kk);
-                const float4 y = *reinterpret_cast<const float4*>(a.codes + static_cast<int64_t>(d_idx[e]) * H + kk);
-                f = make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
-                if (BWD) {
-                    const int64_t r = row0 + e;
-                    if (r < a.n) *reinterpret_cast<float4*>(a.feat + r * H + kk) = f;
-                }
-            }
-            Ft_s[(4 * c + 0) * kBM + e] = f.x;
-            Ft_s[(4 * c + 1) * kBM + e] = f.y;
-            Ft_s[(4 * c + 2) * kBM + e] = f.z;
-            Ft_s[(4 * c + 3) * kBM + e] = f.w;
+        const int kk = k0 + 4 * fc;
+        xreg = make_float4(0.f, 0.f, 0.f, 0.f);
+        yreg = xreg;
+        if (EXACT || kk < H) {
+            xreg = *reinterpret_cast<const float4*>(a.codes + static_cast<int64_t>(my_s) * H + kk);
+            yreg = *reinterpret_cast<const float4*>(a.codes + static_cast<int64_t>(my_d) * H + kk);
         }
-        __syncthreads();
-        // ---- 16 x NT MFMAs: A = W1a (row h), B = features (col e)
+    };
+    auto commit = [&](int k0, int buf) {
+        float* Wt_s = Wt_s0 + buf * kBK * HP;
+        float* Ft_s = Ft_s0 + buf * kBK * kBM;
 #pragma unroll
-        for (int kk = 0; kk < kBK; kk += 2) {
-            const float b = Ft_s[(kk + kh) * kBM + 32 * wave + l31];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float av = Wt_s[(kk + kh) * HP + 32 * t + l31];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[t], 0, 0, 0);
+        for (int j = 0; j < kWV; ++j) {
+            const int i = j * kT + tid;
+            if (EXACT || i < kBK * (HP / 4)) {
+                const int k = i / (HP / 4), h4 = (i % (HP / 4)) * 4;
+                *reinterpret_cast<float4*>(Wt_s + k * HP + h4) = wreg[j];
             }
         }
+        const float4 f = make_float4(xreg.x * yreg.x, xreg.y * yreg.y, xreg.z * yreg.z, xreg.w * yreg.w);
+        if (BWD) {
+            const int64_t r = row0 + fe;
+            const int kk = k0 + 4 * fc;
+            if (r < a.n && (EXACT || kk < H)) *reinterpret_cast<float4*>(a.feat + r * H + kk) = f;
+        }
+        Ft_s[(4 * fc + 0) * kBM + fe] = f.x;
+        Ft_s[(4 * fc + 1) * kBM + fe] = f.y;
+        Ft_s[(4 * fc + 2) * kBM + fe] = f.z;
+        Ft_s[(4 * fc + 3) * kBM + fe] = f.w;
+    };
+    // MFMA operands are register double-buffered one k2-step ahead of their use.
+    float av[2][NTW], bv[2];
+    auto lds_operands = [&](int buf, int kk, int slot) {
+        const float* Wt_s = Wt_s0 + buf * kBK * HP + hh * (HP / 2);
+        const float* Ft_s = Ft_s0 + buf * kBK * kBM;
+        bv[slot] = Ft_s[(kk + kh) * kBM + 32 * eg + l31];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) av[slot][t] = Wt_s[(kk + kh) * HP + 32 * t + l31];
+    };
+
+    fetch(0);
+    commit(0, 0);
+    __syncthreads();
+    int cur = 0;
+#pragma unroll 1
+    for (int k0 = 0; k0 < H; k0 += kBK) {
+        const bool more = k0 + kBK < H;
+        if (more) fetch(k0 + kBK);                 // global loads in flight during the MFMAs
+        lds_operands(cur, 0, 0);
+#pragma unroll
+        for (int st = 0; st < kBK / 2; ++st) {
+            if (st + 1 < kBK / 2) lds_operands(cur, 2 * (st + 1), (st + 1) & 1);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1][t], bv[st & 1], acc[t], 0, 0, 0);
+            if (st == kBK / 4 - 1 && more) commit(k0 + kBK, cur ^ 1);
+        }
+        __syncthreads();                           // next stage complete; everyone done with this one
+        cur ^= 1;
     }
 
-    // ---- epilogue: lane = edge (l31) x half (kh); acc[t][r] is hidden unit 32t + (r&3) + 8(r>>2) + 4kh
-    const int el = 32 * wave + l31;
+    // ---- epilogue: lane = edge (l31) x half (kh); acc[t][r] is hidden unit
+    //      hh*HP/2 + 32t + (r&3) + 8(r>>2) + 4kh of edge row0 + 32eg + l31
+    const int el = 32 * eg + l31;
     const int64_t r = row0 + el;
     const bool live = r < a.n;
-    const int64_t eg = live ? (a.active ? a.active[r] : r) : 0;   // global edge id: dropout row
+    const int64_t eg_id = live ? (a.active ? a.active[r] : r) : 0;   // global edge id: dropout row
+    const uint32_t rkey = dropout_row_key(a.seed, a.site, static_cast<uint64_t>(eg_id));
     const float* Us = a.U + static_cast<int64_t>(s_idx[el]) * H;
     const float* Ud = a.U + static_cast<int64_t>(d_idx[el]) * H;
     float z = 0.f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < NTW; ++t) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int hb = 32 * t + 8 * g + 4 * kh;
-            if (hb < H) {
+            const int hb = hh * (HP / 2) + 32 * t + 8 * g + 4 * kh;
+            if (EXACT || hb < H) {
                 const float4 us = *reinterpret_cast<const float4*>(Us + hb);
                 const float4 ud = *reinterpret_cast<const float4*>(Ud + hb);
                 const float4 bb = *reinterpret_cast<const float4*>(a.b1 + hb);
@@ -160,38 +207,45 @@ __global__ void __launch_bounds__(kT, 2) edge_score_kernel(ScoreArgs a) {
                 const float u4[4] = {us.x - ud.x, us.y - ud.y, us.z - ud.z, us.w - ud.w};
                 const float b4[4] = {bb.x, bb.y, bb.z, bb.w};
                 const float w4[4] = {ww.x, ww.y, ww.z, ww.w};
+                uint32_t bits[2] = {0u, 0u};
+                if (a.use_drop) {
+                    bits[0] = dropout_pair_bits(rkey, static_cast<uint32_t>(hb >> 1));
+                    bits[1] = dropout_pair_bits(rkey, static_cast<uint32_t>((hb >> 1) + 1));
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float v = (acc[t][4 * g + j] + u4[j]) + b4[j];
+                    const float v = (acc[t][4 * g + j] + u4[j]) + b4[j];
                     float m = v > 0.f ? 1.f : 0.f;                 // relu'
-                    if (a.use_drop)
-                        m = dropout_keep_at(a.seed, a.site, static_cast<uint64_t>(eg), static_cast<uint32_t>(hb + j), a.drop_thresh)
-                                ? m * a.drop_scale : 0.f;
+                    if (a.use_drop) {
+                        const uint32_t draw = (j & 1) ? (bits[j >> 1] >> 16) : (bits[j >> 1] & 0xFFFFu);
+                        m = draw >= a.drop_thresh ? m * a.drop_scale : 0.f;
+                    }
                     const float hd = v * m;                          // dropout(relu(v))
                     z = fmaf(w4[j], hd, z);
-                    if (BWD) { acc[t][4 * g + j] = hd; }             // keep for the second epilogue pass
-                    (void)m;
+                    if (BWD) acc[t][4 * g + j] = hd;                 // kept for the second epilogue pass
                 }
             }
         }
     }
     z += __shfl_xor(z, 32, 64);
-    z += a.b2[0];
+    if (kh == 0) zpart[hh * kBM + el] = z;           // fc2 partial over this wave's hidden half
+    __syncthreads();
+    z = (zpart[el] + zpart[kBM + el]) + a.b2[0];
     const float p = 1.0f / (1.0f + expf(-z));
     if (!BWD) {
-        if (live && kh == 0) a.p_out[r] = p;
+        if (live && hh == 0 && kh == 0) a.p_out[r] = p;
         return;
     }
     // ---- backward epilogue: dz = gp p (1-p);  dv = dz w2 relu' keep scale;  hdz = dz hd
     const float dzv = live ? a.gp[r] * p * (1.0f - p) : 0.f;
-    if (live && kh == 0) a.dz[r] = dzv;
+    if (live && hh == 0 && kh == 0) a.dz[r] = dzv;
     if (!live) return;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < NTW; ++t) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int hb = 32 * t + 8 * g + 4 * kh;
-            if (hb < H) {
+            const int hb = hh * (HP / 2) + 32 * t + 8 * g + 4 * kh;
+            if (EXACT || hb < H) {
                 const float4 ww = *reinterpret_cast<const float4*>(a.w2 + hb);
                 const float w4[4] = {ww.x, ww.y, ww.z, ww.w};
                 float dv4[4], hz4[4];
@@ -253,20 +307,34 @@ __global__ void __launch_bounds__(kT) endpoint_reduce(const float* __restrict__ 
     }
 }
 
-inline size_t score_smem_bytes(int NT) { return static_cast<size_t>(kBK) * 32 * NT * 4 + kBK * kBM * 4 + 2 * kBM * 4; }
+inline size_t score_smem_bytes(int NT) { return 2 * (static_cast<size_t>(kBK) * 32 * NT * 4 + kBK * kBM * 4) + 2 * kBM * 4 + 2 * kBM * 4; }
 
 template <bool BWD>
 int launch_score(const ScoreArgs& a, hipStream_t stream) {
     const int H = a.H;
-    const int NT = H <= 32 ? 1 : H <= 64 ? 2 : H <= 128 ? 4 : 8;
+    const int NT = H <= 64 ? 2 : H <= 128 ? 4 : 8;     // hidden units padded to 64 / 128 / 256
     const dim3 grid(static_cast<unsigned>(cdiv(a.n, kBM))), blk(kT);
     const size_t sm = score_smem_bytes(NT);
+    // 2 stages x (16 KiB W + 4 KiB features) at H = 256: 41 KiB per workgroup, three per CU
+    // (an EXACT specialisation that folds the bounds checks makes hipcc 7.2 spill ~200 VGPRs at this
+    //  register budget; the generic variant allocates 151 VGPRs, no scratch, 3 waves/SIMD.)
+    const bool exact = false;
+#define SGS_SCORE_CASE(NT_, EX_)                                                                                   \
+    do {                                                                                                            \
+        static bool raised = false;                                                                                 \
+        if (!raised) {                                                                                              \
+            SGS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_score_kernel<NT_, BWD, EX_>),        \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sm)));      \
+            raised = true;                                                                                          \
+        }                                                                                                           \
+        hipLaunchKernelGGL((edge_score_kernel<NT_, BWD, EX_>), grid, blk, sm, stream, a);                           \
+    } while (0)
     switch (NT) {
-        case 1: hipLaunchKernelGGL((edge_score_kernel<1, BWD>), grid, blk, sm, stream, a); break;
-        case 2: hipLaunchKernelGGL((edge_score_kernel<2, BWD>), grid, blk, sm, stream, a); break;
-        case 4: hipLaunchKernelGGL((edge_score_kernel<4, BWD>), grid, blk, sm, stream, a); break;
-        default: hipLaunchKernelGGL((edge_score_kernel<8, BWD>), grid, blk, sm, stream, a); break;
+        case 2: if (exact) SGS_SCORE_CASE(2, true); else SGS_SCORE_CASE(2, false); break;
+        case 4: if (exact) SGS_SCORE_CASE(4, true); else SGS_SCORE_CASE(4, false); break;
+        default: if (exact) SGS_SCORE_CASE(8, true); else SGS_SCORE_CASE(8, false); break;
     }
+#undef SGS_SCORE_CASE
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

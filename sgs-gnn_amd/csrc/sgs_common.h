@@ -136,27 +136,42 @@ __device__ __forceinline__ float exp_noise_at(uint64_t seed, uint64_t stream_id,
     return -logf(u);
 }
 
-// Dropout keep decision for element (row, col) of dropout site `site`: a murmur-style 64-bit
-// finaliser of (seed, site, row, col) compared against p.  Every fused kernel and the
-// materialising sgs_dropout_keep use this one function, so recompute-in-backward sees the
-// same bits as forward.
+// Dropout keep decision for element (row, col) of dropout site `site`: a 64-bit murmur-style mix of
+// (seed, site, row) gives a 32-bit row key (computed once per row), then a 32-bit murmur3 finaliser
+// of (row key, col pair) gives two 16-bit draws compared against p * 2^16.  Every fused kernel and the materialising
+// sgs_dropout_keep use these two functions, so recompute-in-backward sees the same bits as forward.
 __host__ __device__ __forceinline__ uint32_t mix64to32(uint64_t z) {
     z ^= z >> 33; z *= 0xff51afd7ed558ccdULL;
     z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ULL;
     z ^= z >> 33;
     return static_cast<uint32_t>(z >> 32);
 }
-__host__ __device__ __forceinline__ bool dropout_keep_at(uint64_t seed, uint32_t site, uint64_t row, uint32_t col,
-                                                         uint32_t thresh /* = p * 2^32 */) {
+__host__ __device__ __forceinline__ uint32_t dropout_row_key(uint64_t seed, uint32_t site, uint64_t row) {
     uint64_t z = seed ^ (0x9E3779B97F4A7C15ULL * (static_cast<uint64_t>(site) + 1));
     z = (z ^ row) * 0xD6E8FEB86659FD93ULL;
-    z ^= static_cast<uint64_t>(col) * 0xA24BAED4963EE407ULL;
-    return mix64to32(z) >= thresh;
+    return mix64to32(z);
+}
+// One murmur3 finaliser yields 32 random bits = two 16-bit draws: columns 2j and 2j+1 share a hash.
+// P(drop) = round(p * 65536) / 65536.
+__host__ __device__ __forceinline__ uint32_t dropout_pair_bits(uint32_t row_key, uint32_t col_pair) {
+    uint32_t h = row_key ^ (col_pair * 0x9E3779B1u);
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+__host__ __device__ __forceinline__ bool dropout_keep_col(uint32_t row_key, uint32_t col, uint32_t thresh16 /* = p * 2^16 */) {
+    const uint32_t h = dropout_pair_bits(row_key, col >> 1);
+    return ((col & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= thresh16;
+}
+__host__ __device__ __forceinline__ bool dropout_keep_at(uint64_t seed, uint32_t site, uint64_t row, uint32_t col,
+                                                         uint32_t thresh) {
+    return dropout_keep_col(dropout_row_key(seed, site, row), col, thresh);
 }
 __host__ __device__ __forceinline__ uint32_t dropout_thresh(float p) {
-    double t = static_cast<double>(p) * 4294967296.0;
+    double t = static_cast<double>(p) * 65536.0 + 0.5;
     if (t < 0) t = 0;
-    if (t > 4294967295.0) t = 4294967295.0;
+    if (t > 65535.0) t = 65535.0;
     return static_cast<uint32_t>(t);
 }
 

@@ -1,0 +1,22 @@
+"""Launch the dominant kernel (fused edge scorer, forward) a few times on a Reddit-partition-sized
+input -- the target of `rocprofv3 --pmc ...` passes (profiles/README.md)."""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sgs_gnn_amd as S
+
+dev = "cuda:0"
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 351194
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+N, H = 1013, 256
+g = torch.Generator(device=dev).manual_seed(0)
+codes = torch.relu(torch.randn(N, H, device=dev, generator=g))
+ei = torch.randint(0, N, (2, E), device=dev, generator=g)
+fc1 = torch.nn.Linear(2 * H, H).to(dev)
+fc2 = torch.nn.Linear(H, 1).to(dev)
+with torch.no_grad():
+    for _ in range(reps):
+        p = S.ops.edge_score(codes, fc1.weight, fc1.bias, fc2.weight, fc2.bias, ei, p=0.3, seed=1, site=2)
+torch.cuda.synchronize()
+print("ok", float(p.mean()))
