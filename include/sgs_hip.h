@@ -153,19 +153,20 @@ int sgs_gcn_norm_bwd(const float* w, const float* gw_hat, const float* gloop, in
  * act: identity | ReLU | ReLU then counter-based dropout(p, seed, site) (see sgs_dropout_keep).
  * Forward uses (in_ptr, in_src, what_in, what_loop); the transposed product of backward,
  * dX = A_hat^T dZ, is the same call with (out_ptr, out_dst, what_out, what_loop).
- * diag / bias may be NULL.  X is the already linearly transformed feature matrix [N,D]
+ * diag / bias may be NULL; nnz = ptr[N] (known to the caller; picks the row-per-workgroup kernel for
+ * few long rows).  X is the already linearly transformed feature matrix [N,D]
  * (the dense X W^T is a library GEMM on the host side).
  * ---------------------------------------------------------------------------------- */
 #define SGS_ACT_NONE 0
 #define SGS_ACT_RELU 1
 #define SGS_ACT_RELU_DROPOUT 2
-int sgs_spmm_csr(const float* X, int64_t N, int64_t D, const int32_t* ptr, const int32_t* col, const float* val,
+int sgs_spmm_csr(const float* X, int64_t N, int64_t D, int64_t nnz, const int32_t* ptr, const int32_t* col, const float* val,
                  const float* diag, const float* bias, int act, float p_drop, uint64_t seed, uint32_t site, float* Y,
                  sgs_stream_t stream);
 
 /* SDDMM over the same CSR (gradient wrt the normalised weights):
  *   g[eid[k]] = <A[i,:], B[col[k],:]> for k in row i;  gdiag[i] = <A[i,:], B[i,:]>  (gdiag may be NULL) */
-int sgs_sddmm_csr(const float* A, const float* B, int64_t N, int64_t D, const int32_t* ptr, const int32_t* col,
+int sgs_sddmm_csr(const float* A, const float* B, int64_t N, int64_t D, int64_t nnz, const int32_t* ptr, const int32_t* col,
                   const int32_t* eid, float* g, float* gdiag, sgs_stream_t stream);
 
 /* dZ = dY * act'(Y) for the fused epilogue above (Y is the layer OUTPUT: Y > 0 iff kept and
@@ -208,7 +209,7 @@ int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64
                             const float* W1, const float* b1, const float* w2, const float* b2, float p_drop,
                             uint64_t seed, uint32_t site, float* dv, float* hdz, float* dz, float* feat, void* ws,
                             size_t ws_bytes, sgs_stream_t stream);
-int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, int64_t N, int64_t H,
+int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, int64_t N, int64_t H, int64_t nnz,
                         const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid, const int32_t* out_ptr,
                         const int32_t* out_dst, const int32_t* out_eid, float sign_out, float sign_in, float* out,
                         sgs_stream_t stream);

@@ -14,6 +14,8 @@
 // k-step a workgroup stages W1a^T[k0:k0+32][0:H] (coalesced, k-major) and the 128x32 feature
 // tile ([k][e] image, conflict-free ds_read_b32 for the B operand) in LDS.
 // Roofline: MFMA-bound (4 H^2 / 2 flops per edge after the split vs ~4 KB of L2 traffic).
+#include <type_traits>
+
 #include "sgs_common.h"
 
 namespace sgs {
@@ -307,6 +309,65 @@ __global__ void __launch_bounds__(kT) endpoint_reduce(const float* __restrict__ 
     }
 }
 
+// Small-N variant: a 4-wave workgroup per node; the node's out-row then in-row entries form one list
+// that the waves stride with four independent row gathers in flight each; partial sums meet in LDS
+// in a fixed order (deterministic).
+template <int VEC, bool HAS_T>
+__global__ void __launch_bounds__(kT) endpoint_reduce_rowblock(const float* __restrict__ Mo, const float* __restrict__ Mi,
+                                                              const float* __restrict__ T, int64_t N, int64_t H,
+                                                              const int* __restrict__ in_ptr, const int* __restrict__ in_src,
+                                                              const int* __restrict__ in_eid, const int* __restrict__ out_ptr,
+                                                              const int* __restrict__ out_dst, const int* __restrict__ out_eid,
+                                                              float sgn_out, float sgn_in, float* __restrict__ out) {
+    using V = typename std::conditional<VEC == 4, float4, float>::type;
+    __shared__ float part[4][64 * VEC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t v = blockIdx.x;
+    const int ob = out_ptr[v], no = out_ptr[v + 1] - ob;
+    const int ib = in_ptr[v], ni = in_ptr[v + 1] - ib;
+    const int total = no + ni;
+    for (int64_t cbase = 0; cbase < H; cbase += 64 * VEC) {
+        const int64_t c0 = cbase + static_cast<int64_t>(lane) * VEC;
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+        if (c0 < H) {
+            for (int k0 = wave; k0 < total; k0 += 16) {
+                float m[4][VEC], t[4][VEC], sg[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + 4 * u;
+                    sg[u] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) { m[u][j] = 0.f; t[u][j] = 1.f; }
+                    if (k < total) {
+                        const bool isout = k < no;
+                        const int idx = isout ? ob + k : ib + (k - no);
+                        const int er = isout ? out_eid[idx] : in_eid[idx];
+                        const float* M = isout ? Mo : Mi;
+                        sg[u] = isout ? sgn_out : sgn_in;
+                        *reinterpret_cast<V*>(m[u]) = *reinterpret_cast<const V*>(M + static_cast<int64_t>(er) * H + c0);
+                        if (HAS_T) {
+                            const int cr = isout ? out_dst[idx] : in_src[idx];
+                            *reinterpret_cast<V*>(t[u]) = *reinterpret_cast<const V*>(T + static_cast<int64_t>(cr) * H + c0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) acc[j] = fmaf(sg[u] * m[u][j], t[u][j], acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) part[wave][lane * VEC + j] = acc[j];
+        __syncthreads();
+        const int tt = threadIdx.x;
+        if (tt < 64 * VEC && cbase + tt < H) out[v * H + cbase + tt] = (part[0][tt] + part[1][tt]) + (part[2][tt] + part[3][tt]);
+        __syncthreads();
+    }
+}
+
 inline size_t score_smem_bytes(int NT) { return 2 * (static_cast<size_t>(kBK) * 32 * NT * 4 + kBK * kBM * 4) + 2 * kBM * 4 + 2 * kBM * 4; }
 
 template <bool BWD>
@@ -401,8 +462,8 @@ int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64
     return launch_score<true>(a, stream);
 }
 
-int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, int64_t N, int64_t H, const int32_t* in_ptr,
-                        const int32_t* in_src,
+int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, int64_t N, int64_t H, int64_t nnz,
+                        const int32_t* in_ptr, const int32_t* in_src,
                         const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
                         float sign_out, float sign_in, float* out, sgs_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -412,7 +473,20 @@ int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, i
     const bool v4 = H % 4 == 0 && (reinterpret_cast<uintptr_t>(M_out) & 15) == 0 && (reinterpret_cast<uintptr_t>(M_in) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
                     (!T || (reinterpret_cast<uintptr_t>(T) & 15) == 0);
-    const dim3 grid(static_cast<unsigned>(cdiv(N * 64, kT))), blk(kT);
+    const dim3 blk(kT);
+    if (N <= 65536 && nnz >= 8 * N) {         // few, long rows: a workgroup per node
+        const dim3 grid(static_cast<unsigned>(N));
+        if (v4) {
+            if (T) hipLaunchKernelGGL((endpoint_reduce_rowblock<4, true>), grid, blk, 0, stream, M_out, M_in, T, N, H, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, sign_out, sign_in, out);
+            else   hipLaunchKernelGGL((endpoint_reduce_rowblock<4, false>), grid, blk, 0, stream, M_out, M_in, T, N, H, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, sign_out, sign_in, out);
+        } else {
+            if (T) hipLaunchKernelGGL((endpoint_reduce_rowblock<1, true>), grid, blk, 0, stream, M_out, M_in, T, N, H, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, sign_out, sign_in, out);
+            else   hipLaunchKernelGGL((endpoint_reduce_rowblock<1, false>), grid, blk, 0, stream, M_out, M_in, T, N, H, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, sign_out, sign_in, out);
+        }
+        SGS_LAUNCH_OK();
+        return SGS_OK;
+    }
+    const dim3 grid(static_cast<unsigned>(cdiv(N * 64, kT)));
     if (v4) {
         if (T) hipLaunchKernelGGL((endpoint_reduce<4, true>), grid, blk, 0, stream, M_out, M_in, T, N, H, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, sign_out, sign_in, out);
         else   hipLaunchKernelGGL((endpoint_reduce<4, false>), grid, blk, 0, stream, M_out, M_in, T, N, H, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, sign_out, sign_in, out);

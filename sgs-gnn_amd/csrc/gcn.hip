@@ -311,6 +311,71 @@ __global__ void __launch_bounds__(kT) spmm_csr(const float* __restrict__ X, int6
     }
 }
 
+// Small-N variant (METIS partitions: ~1k rows of ~100-1000 nnz): one wave per row leaves the chip
+// mostly empty and hub rows serialise, so a 4-wave workgroup owns a row, each wave gathers a strided
+// quarter of its nnz (8 rows in flight per wave) and the four partial sums are combined through LDS
+// in a fixed order (deterministic).
+template <int VEC>
+__global__ void __launch_bounds__(kT) spmm_csr_rowblock(const float* __restrict__ X, int64_t N, int64_t D, const int* __restrict__ ptr,
+                                                       const int* __restrict__ col, const float* __restrict__ val,
+                                                       const float* __restrict__ diag, const float* __restrict__ bias, int act,
+                                                       float drop_scale, uint32_t drop_thresh, uint64_t seed, uint32_t site,
+                                                       float* __restrict__ Y) {
+    using V = typename VecT<VEC>::type;
+    __shared__ float part[4][64 * VEC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = blockIdx.x;
+    const int b = ptr[i], e = ptr[i + 1];
+    const float dg = diag ? diag[i] : 0.f;
+    const uint32_t rkey = dropout_row_key(seed, site, static_cast<uint64_t>(i));
+    for (int64_t cbase = 0; cbase < D; cbase += 64 * VEC) {
+        const int64_t c0 = cbase + static_cast<int64_t>(lane) * VEC;
+        const bool in = c0 < D;
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        if (in) {
+            int k = b + wave;
+            for (; k + 28 < e; k += 32) {            // 8 independent gathers (k, k+4, ..., k+28)
+                int j[8]; float w[8]; V x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { j[u] = col[k + 4 * u]; w[u] = val[k + 4 * u]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const V*>(X + static_cast<int64_t>(j[u]) * D + c0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    float xv[VEC];
+                    *reinterpret_cast<V*>(xv) = x[u];
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w[u], xv[v], acc[v]);
+                }
+            }
+            for (; k < e; k += 4) {
+                float xv[VEC];
+                *reinterpret_cast<V*>(xv) = *reinterpret_cast<const V*>(X + static_cast<int64_t>(col[k]) * D + c0);
+                const float w = val[k];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w, xv[v], acc[v]);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) part[wave][lane * VEC + v] = acc[v];
+        __syncthreads();
+        // 64*VEC columns finished by the first 64*VEC threads
+        const int t = threadIdx.x;
+        if (t < 64 * VEC && cbase + t < D) {
+            const int64_t c = cbase + t;
+            float y = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+            if (diag) y = fmaf(dg, X[i * D + c], y);
+            if (bias) y += bias[c];
+            if (act != SGS_ACT_NONE) y = fmaxf(y, 0.f);
+            if (act == SGS_ACT_RELU_DROPOUT) y = dropout_keep_col(rkey, static_cast<uint32_t>(c), drop_thresh) ? y * drop_scale : 0.f;
+            Y[i * D + c] = y;
+        }
+        __syncthreads();
+    }
+}
+
 // SDDMM over the CSR: g[eid[k]] = <A[i,:], B[col[k],:]> for k in row i ; gdiag[i] = <A[i,:], B[i,:]>.
 template <int VEC, int LPR>
 __global__ void __launch_bounds__(kT) sddmm_csr(const float* __restrict__ A, const float* __restrict__ B, int64_t N, int64_t D,
@@ -347,6 +412,45 @@ __global__ void __launch_bounds__(kT) sddmm_csr(const float* __restrict__ A, con
             if (is_edge) g[eid[k]] = acc;
             else if (is_diag && gdiag) gdiag[i] = acc;
         }
+    }
+}
+
+// Small-N variant of sddmm_csr: a 4-wave workgroup per row, waves stride the row's entries, two
+// independent dot products in flight per wave.
+template <int VEC>
+__global__ void __launch_bounds__(kT) sddmm_csr_rowblock(const float* __restrict__ A, const float* __restrict__ B, int64_t N, int64_t D,
+                                                        const int* __restrict__ ptr, const int* __restrict__ col,
+                                                        const int* __restrict__ eid, float* __restrict__ g, float* __restrict__ gdiag) {
+    using V = typename VecT<VEC>::type;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = blockIdx.x;
+    const int b = ptr[i], e = ptr[i + 1];
+    const float* Ai = A + i * D;
+    auto dot = [&](int64_t j) {
+        float acc = 0.f;
+        for (int64_t c0 = static_cast<int64_t>(lane) * VEC; c0 < D; c0 += 64 * VEC) {
+            float a[VEC], x[VEC];
+            *reinterpret_cast<V*>(a) = *reinterpret_cast<const V*>(Ai + c0);
+            *reinterpret_cast<V*>(x) = *reinterpret_cast<const V*>(B + j * D + c0);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc = fmaf(a[v], x[v], acc);
+        }
+        return acc;
+    };
+    int k = b + wave;
+    for (; k + 4 < e; k += 8) {
+        float d0 = dot(col[k]), d1 = dot(col[k + 4]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { d0 += __shfl_xor(d0, o, 64); d1 += __shfl_xor(d1, o, 64); }
+        if (lane == 0) { g[eid[k]] = d0; g[eid[k + 4]] = d1; }
+    }
+    for (; k < e; k += 4) {
+        const float d0 = wave_sum_all(dot(col[k]));
+        if (lane == 0) g[eid[k]] = d0;
+    }
+    if (wave == 0 && gdiag) {
+        const float d0 = wave_sum_all(dot(i));
+        if (lane == 0) gdiag[i] = d0;
     }
 }
 
@@ -511,7 +615,7 @@ int sgs_gcn_norm_bwd(const float* w, const float* gw_hat, const float* gloop, in
     return SGS_OK;
 }
 
-int sgs_spmm_csr(const float* X, int64_t N, int64_t D, const int32_t* ptr, const int32_t* col, const float* val,
+int sgs_spmm_csr(const float* X, int64_t N, int64_t D, int64_t nnz, const int32_t* ptr, const int32_t* col, const float* val,
                  const float* diag, const float* bias, int act, float p_drop, uint64_t seed, uint32_t site, float* Y,
                  sgs_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -525,12 +629,21 @@ int sgs_spmm_csr(const float* X, int64_t N, int64_t D, const int32_t* ptr, const
     const float scale = 1.0f / (1.0f - p_drop);
     const uint32_t th = dropout_thresh(p_drop);
     if (act == SGS_ACT_RELU_DROPOUT && p_drop == 0.f) act = SGS_ACT_RELU;
-    DISPATCH_VEC_LPR(spmm_csr, vec, lpr, N, X, N, D, ptr, col, val, diag, bias, act, scale, th, seed, site, Y);
+    if (N <= 65536 && nnz >= 16 * N) {        // few, long rows: a workgroup per row
+        if (vec == 4)
+            hipLaunchKernelGGL((spmm_csr_rowblock<4>), dim3(static_cast<unsigned>(N)), dim3(kT), 0, stream, X, N, D, ptr, col, val,
+                               diag, bias, act, scale, th, seed, site, Y);
+        else
+            hipLaunchKernelGGL((spmm_csr_rowblock<1>), dim3(static_cast<unsigned>(N)), dim3(kT), 0, stream, X, N, D, ptr, col, val,
+                               diag, bias, act, scale, th, seed, site, Y);
+    } else {
+        DISPATCH_VEC_LPR(spmm_csr, vec, lpr, N, X, N, D, ptr, col, val, diag, bias, act, scale, th, seed, site, Y);
+    }
     SGS_LAUNCH_OK();
     return SGS_OK;
 }
 
-int sgs_sddmm_csr(const float* A, const float* B, int64_t N, int64_t D, const int32_t* ptr, const int32_t* col,
+int sgs_sddmm_csr(const float* A, const float* B, int64_t N, int64_t D, int64_t nnz, const int32_t* ptr, const int32_t* col,
                   const int32_t* eid, float* g, float* gdiag, sgs_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     SGS_REQUIRE(N >= 0 && D >= 0, SGS_EINVAL, "sgs_sddmm_csr: bad sizes");
@@ -538,7 +651,12 @@ int sgs_sddmm_csr(const float* A, const float* B, int64_t N, int64_t D, const in
     SGS_REQUIRE(A && B && ptr, SGS_EINVAL, "sgs_sddmm_csr: null pointer");
     const int vec = (D % 4 == 0 && aligned16(A) && aligned16(B)) ? 4 : 1;
     const int lpr = pick_lpr(D, vec);
-    DISPATCH_VEC_LPR(sddmm_csr, vec, lpr, N, A, B, N, D, ptr, col, eid, g, gdiag);
+    if (N <= 65536 && nnz >= 16 * N) {
+        if (vec == 4) hipLaunchKernelGGL((sddmm_csr_rowblock<4>), dim3(static_cast<unsigned>(N)), dim3(kT), 0, stream, A, B, N, D, ptr, col, eid, g, gdiag);
+        else          hipLaunchKernelGGL((sddmm_csr_rowblock<1>), dim3(static_cast<unsigned>(N)), dim3(kT), 0, stream, A, B, N, D, ptr, col, eid, g, gdiag);
+    } else {
+        DISPATCH_VEC_LPR(sddmm_csr, vec, lpr, N, A, B, N, D, ptr, col, eid, g, gdiag);
+    }
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

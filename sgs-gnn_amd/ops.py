@@ -239,10 +239,10 @@ def gcn_norm(graph: Graph, w=None) -> Norm:
     return nm
 
 
-def _spmm(X, ptr, col, val, diag, bias, act, p, seed, site, N, D):
+def _spmm(X, ptr, col, val, diag, bias, act, p, seed, site, N, D, nnz):
     L = _lib.lib()
     Y = torch.empty(N, D, dtype=torch.float32, device=X.device)
-    _lib.check(L.sgs_spmm_csr(_ptr(X, torch.float32), N, D, _ptr(ptr), _ptr(col), _ptr(val), _ptr(diag), _ptr(bias),
+    _lib.check(L.sgs_spmm_csr(_ptr(X, torch.float32), N, D, nnz, _ptr(ptr), _ptr(col), _ptr(val), _ptr(diag), _ptr(bias),
                               act, float(p), seed, site, _ptr(Y), _stream()), "sgs_spmm_csr")
     return Y
 
@@ -254,7 +254,7 @@ class _Propagate(torch.autograd.Function):
     def forward(ctx, X, handle, bias, nm, act, p, seed, site):
         gr = nm.graph
         N, D = X.shape
-        Y = _spmm(X, gr.in_ptr, gr.in_src, nm.what_in, nm.what_loop, bias, act, p, seed, site, N, D)
+        Y = _spmm(X, gr.in_ptr, gr.in_src, nm.what_in, nm.what_loop, bias, act, p, seed, site, N, D, gr.n_edges)
         ctx.nm, ctx.act, ctx.p = nm, act, p
         ctx.has_bias, ctx.has_handle = bias is not None, handle is not None
         ctx.save_for_backward(X, Y if act != ACT_NONE else None)
@@ -274,11 +274,11 @@ class _Propagate(torch.autograd.Function):
             dZ = dY
         dX = dbias = g = None
         if ctx.needs_input_grad[0]:
-            dX = _spmm(dZ, gr.out_ptr, gr.out_dst, nm.what_out, nm.what_loop, None, ACT_NONE, 0.0, 0, 0, N, D)
+            dX = _spmm(dZ, gr.out_ptr, gr.out_dst, nm.what_out, nm.what_loop, None, ACT_NONE, 0.0, 0, 0, N, D, gr.n_edges)
         if ctx.has_handle and ctx.needs_input_grad[1]:
             g = torch.empty(gr.n_edges + gr.N, dtype=torch.float32, device=dY.device)
             gw, gl = g[:gr.n_edges], g[gr.n_edges:]
-            _lib.check(L.sgs_sddmm_csr(_ptr(dZ), _ptr(X), N, D, _ptr(gr.in_ptr), _ptr(gr.in_src), _ptr(gr.in_eid),
+            _lib.check(L.sgs_sddmm_csr(_ptr(dZ), _ptr(X), N, D, gr.n_edges, _ptr(gr.in_ptr), _ptr(gr.in_src), _ptr(gr.in_eid),
                                        gw.data_ptr(), gl.data_ptr(), _stream()), "sgs_sddmm_csr")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = _colsum(dZ)
@@ -320,7 +320,7 @@ def _colsum(A):
 def _endpoint_reduce(M_out, M_in, T, graph: Graph, s_out, s_in, H):
     L = _lib.lib()
     out = torch.empty(graph.N, H, dtype=torch.float32, device=M_out.device)
-    _lib.check(L.sgs_endpoint_reduce(_ptr(M_out), _ptr(M_in), _ptr(T), graph.N, H, _ptr(graph.in_ptr), _ptr(graph.in_src), _ptr(graph.in_eid),
+    _lib.check(L.sgs_endpoint_reduce(_ptr(M_out), _ptr(M_in), _ptr(T), graph.N, H, graph.n_edges, _ptr(graph.in_ptr), _ptr(graph.in_src), _ptr(graph.in_eid),
                                      _ptr(graph.out_ptr), _ptr(graph.out_dst), _ptr(graph.out_eid), float(s_out), float(s_in),
                                      _ptr(out), _stream()), "sgs_endpoint_reduce")
     return out
