@@ -247,6 +247,29 @@ int sgs_edge_reg_bwd(const float* w, const int64_t* sampled_edge_index, int64_t 
                      int64_t C, const int64_t* y, const uint8_t* train_mask, const float* out, float coef1,
                      float coef2, const float* grad_loss, float* dw, float* Gs, float* Gd, sgs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * K8: GAT attention (PyG 2.3.1 GATConv, heads = 1; model.py:189-208 via torch_geometric's GAT):
+ *   e_k = leaky_relu(a_src[src_k] + a_dst[dst_k], slope) over each node's in-edges + one self loop
+ *   (existing (i,i) edges are ignored, as PyG removes them), soft = softmax per destination
+ *   (denominator + 1e-16), alpha = dropout(soft, p) keyed by (seed, site, edge id) / (site+1, node).
+ * sgs_gat_alpha_fwd writes soft/alpha in dst-CSR entry order (+ per-node loop values); the aggregation
+ * out = sum_k alpha_k x'[src_k] + alpha_loop x'[i] + bias is sgs_spmm_csr(val = alpha_in, diag =
+ * alpha_loop); backward: galpha (per edge id) / gloop from sgs_sddmm_csr, then sgs_gat_alpha_bwd gives
+ * g_edge[eid] = dL/d(a_src[src]+a_dst[dst]) per edge, g_selfloop[i], and d_a_dst[i]; d_a_src is the
+ * per-source sum of g_edge (sgs_spmm_csr over the src-CSR with D = 1) + g_selfloop.
+ * sgs_gather_by_eid / sgs_scatter_by_eid re-order per-edge arrays between edge-id and CSR entry order.
+ * ---------------------------------------------------------------------------------- */
+int sgs_gat_alpha_fwd(const float* a_src, const float* a_dst, int64_t N, int64_t n_edges, const int32_t* in_ptr,
+                      const int32_t* in_src, const int32_t* in_eid, float negative_slope, float p_drop, uint64_t seed,
+                      uint32_t site, float* soft_in, float* soft_loop, float* alpha_in, float* alpha_loop,
+                      sgs_stream_t stream);
+int sgs_gat_alpha_bwd(const float* a_src, const float* a_dst, int64_t N, int64_t n_edges, const int32_t* in_ptr,
+                      const int32_t* in_src, const int32_t* in_eid, float negative_slope, float p_drop, uint64_t seed,
+                      uint32_t site, const float* soft_in, const float* soft_loop, const float* galpha,
+                      const float* gloop, float* g_edge, float* g_selfloop, float* d_a_dst, sgs_stream_t stream);
+int sgs_gather_by_eid(const float* by_eid, const int32_t* eid, int64_t n, float* out_order, sgs_stream_t stream);
+int sgs_scatter_by_eid(const float* in_order, const int32_t* eid, int64_t n, float* by_eid, sgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

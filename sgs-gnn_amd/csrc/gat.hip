@@ -1,0 +1,189 @@
+// K8: GAT attention (PyG 2.3.1 GATConv, heads = 1) over the dst-sorted CSR (gfx950).
+//
+// Reference: model.py:189-208 builds torch_geometric.nn.models.GAT(num_layers=2, act='relu',
+// dropout=p); each GATConv layer is
+//   x' = lin(x);  a_s = <x', att_src>, a_d = <x', att_dst>                  (node level, host side)
+//   existing self loops removed, one loop per node added
+//   e_k = leaky_relu(a_s[src_k] + a_d[dst_k], 0.2);  alpha = softmax over each node's in-edges
+//   alpha = dropout(alpha, p)  (training);  out[i] = sum_k alpha_k x'[src_k] + bias
+// `edge_weight` is ignored by PyG's GAT (supports_edge_weight = False).
+// The aggregation itself reuses sgs_spmm_csr (val = alpha, diag = loop alpha); this file holds the
+// segment softmax and its backward.  One wave per destination node; rows are walked three times
+// (max, sum, normalise) from L2.
+#include "sgs_common.h"
+
+namespace sgs {
+namespace {
+
+constexpr int kT = 256;
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : slope * v; }
+
+// alpha_in[k] (dst-CSR order; 0 for (i,i) entries), alpha_loop[i]: post-softmax, post-dropout weights;
+// soft_in / soft_loop: the pre-dropout softmax values kept for backward.
+__global__ void __launch_bounds__(kT) gat_alpha_fwd(const float* __restrict__ a_s, const float* __restrict__ a_d, int64_t N,
+                                                   const int* __restrict__ in_ptr, const int* __restrict__ in_src,
+                                                   const int* __restrict__ in_eid, float slope, float drop_scale,
+                                                   uint32_t drop_thresh, int use_drop, uint64_t seed, uint32_t site,
+                                                   float* __restrict__ soft_in, float* __restrict__ soft_loop,
+                                                   float* __restrict__ alpha_in, float* __restrict__ alpha_loop) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
+    if (i >= N) return;
+    const int b = in_ptr[i], e = in_ptr[i + 1];
+    const float ad = a_d[i];
+    const float eloop = lrelu(a_s[i] + ad, slope);
+    float mx = eloop;
+    for (int k = b + lane; k < e; k += 64) {
+        const int s = in_src[k];
+        if (s != static_cast<int>(i)) mx = fmaxf(mx, lrelu(a_s[s] + ad, slope));
+    }
+    mx = wave_max_all(mx);
+    float sum = 0.f;
+    for (int k = b + lane; k < e; k += 64) {
+        const int s = in_src[k];
+        if (s != static_cast<int>(i)) sum += expf(lrelu(a_s[s] + ad, slope) - mx);
+    }
+    sum = wave_sum_all(sum) + expf(eloop - mx);
+    const float inv = 1.0f / (sum + 1e-16f);                  // torch_geometric.utils.softmax: / (sum + 1e-16)
+    // attention dropout is keyed by (site, row = edge id) for edges and (site + 1, row = node) for loops
+    for (int k = b + lane; k < e; k += 64) {
+        const int s = in_src[k];
+        float sm = 0.f, al = 0.f;
+        if (s != static_cast<int>(i)) {
+            sm = expf(lrelu(a_s[s] + ad, slope) - mx) * inv;
+            al = sm;
+            if (use_drop) al = dropout_keep_at(seed, site, static_cast<uint64_t>(in_eid[k]), 0u, drop_thresh) ? sm * drop_scale : 0.f;
+        }
+        soft_in[k] = sm;
+        alpha_in[k] = al;
+    }
+    if (lane == 0) {
+        const float sm = expf(eloop - mx) * inv;
+        float al = sm;
+        if (use_drop) al = dropout_keep_at(seed, site + 1u, static_cast<uint64_t>(i), 0u, drop_thresh) ? sm * drop_scale : 0.f;
+        soft_loop[i] = sm;
+        alpha_loop[i] = al;
+    }
+}
+
+// Backward of dropout + softmax + leaky_relu for one destination row:
+//   dal_k  = galpha[eid_k] (gradient wrt the dropped alpha; from sgs_sddmm_csr) , dloop = gloop[i]
+//   dsm_k  = dal_k * keep_k * scale ;  dot = sum_k sm_k dsm_k (incl. loop)
+//   de_k   = sm_k (dsm_k - dot) ;  dpre_k = de_k * (pre_k > 0 ? 1 : slope)
+//   ge[eid_k] = dpre_k (-> d a_s[src_k], summed per source by the caller) ; d a_d[i] = sum_k dpre_k ;
+//   gsl[i] = dpre_loop  (the loop's contribution to d a_s[i])
+__global__ void __launch_bounds__(kT) gat_alpha_bwd(const float* __restrict__ a_s, const float* __restrict__ a_d, int64_t N,
+                                                   const int* __restrict__ in_ptr, const int* __restrict__ in_src,
+                                                   const int* __restrict__ in_eid, float slope, float drop_scale,
+                                                   uint32_t drop_thresh, int use_drop, uint64_t seed, uint32_t site,
+                                                   const float* __restrict__ soft_in, const float* __restrict__ soft_loop,
+                                                   const float* __restrict__ galpha, const float* __restrict__ gloop,
+                                                   float* __restrict__ ge, float* __restrict__ gsl, float* __restrict__ d_ad) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
+    if (i >= N) return;
+    const int b = in_ptr[i], e = in_ptr[i + 1];
+    const float ad = a_d[i];
+    auto dsm_edge = [&](int k) {
+        float g = galpha[in_eid[k]];
+        if (use_drop) g = dropout_keep_at(seed, site, static_cast<uint64_t>(in_eid[k]), 0u, drop_thresh) ? g * drop_scale : 0.f;
+        return g;
+    };
+    float gl = gloop[i];
+    if (use_drop) gl = dropout_keep_at(seed, site + 1u, static_cast<uint64_t>(i), 0u, drop_thresh) ? gl * drop_scale : 0.f;
+    float dot = 0.f;
+    for (int k = b + lane; k < e; k += 64)
+        if (in_src[k] != static_cast<int>(i)) dot += soft_in[k] * dsm_edge(k);
+    dot = wave_sum_all(dot) + soft_loop[i] * gl;
+    float dad = 0.f;
+    for (int k = b + lane; k < e; k += 64) {
+        const int s = in_src[k];
+        float dpre = 0.f;
+        if (s != static_cast<int>(i)) {
+            const float pre = a_s[s] + ad;
+            dpre = soft_in[k] * (dsm_edge(k) - dot) * (pre > 0.f ? 1.f : slope);
+        }
+        ge[in_eid[k]] = dpre;
+        dad += dpre;
+    }
+    dad = wave_sum_all(dad);
+    if (lane == 0) {
+        const float pre = a_s[i] + ad;
+        const float dl = soft_loop[i] * (gl - dot) * (pre > 0.f ? 1.f : slope);
+        gsl[i] = dl;
+        d_ad[i] = dad + dl;
+    }
+}
+
+// out_order[k] = by_eid[eid[k]]  (re-order a per-edge array into a CSR's entry order)
+__global__ void __launch_bounds__(kT) gather_by_eid(const float* __restrict__ by_eid, const int* __restrict__ eid, int64_t n,
+                                                   float* __restrict__ out_order) {
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (k < n) out_order[k] = by_eid[eid[k]];
+}
+__global__ void __launch_bounds__(kT) scatter_by_eid(const float* __restrict__ in_order, const int* __restrict__ eid, int64_t n,
+                                                    float* __restrict__ by_eid) {
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (k < n) by_eid[eid[k]] = in_order[k];
+}
+
+}  // namespace
+}  // namespace sgs
+
+using namespace sgs;
+
+extern "C" {
+
+int sgs_gat_alpha_fwd(const float* a_src, const float* a_dst, int64_t N, int64_t n_edges, const int32_t* in_ptr,
+                      const int32_t* in_src, const int32_t* in_eid, float negative_slope, float p_drop, uint64_t seed,
+                      uint32_t site, float* soft_in, float* soft_loop, float* alpha_in, float* alpha_loop,
+                      sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && n_edges >= 0 && p_drop >= 0.f && p_drop < 1.f, SGS_EINVAL, "sgs_gat_alpha_fwd: bad arguments");
+    if (N == 0) return SGS_OK;
+    SGS_REQUIRE(a_src && a_dst && in_ptr && soft_loop && alpha_loop && (n_edges == 0 || (in_src && in_eid && soft_in && alpha_in)),
+                SGS_EINVAL, "sgs_gat_alpha_fwd: null pointer");
+    hipLaunchKernelGGL(gat_alpha_fwd, dim3(cdiv(N * 64, kT)), dim3(kT), 0, stream, a_src, a_dst, N, in_ptr, in_src, in_eid,
+                       negative_slope, 1.0f / (1.0f - p_drop), dropout_thresh(p_drop), p_drop > 0.f ? 1 : 0, seed, site, soft_in,
+                       soft_loop, alpha_in, alpha_loop);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_gat_alpha_bwd(const float* a_src, const float* a_dst, int64_t N, int64_t n_edges, const int32_t* in_ptr,
+                      const int32_t* in_src, const int32_t* in_eid, float negative_slope, float p_drop, uint64_t seed,
+                      uint32_t site, const float* soft_in, const float* soft_loop, const float* galpha, const float* gloop,
+                      float* g_edge, float* g_selfloop, float* d_a_dst, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && n_edges >= 0 && p_drop >= 0.f && p_drop < 1.f, SGS_EINVAL, "sgs_gat_alpha_bwd: bad arguments");
+    if (N == 0) return SGS_OK;
+    SGS_REQUIRE(a_src && a_dst && in_ptr && soft_loop && gloop && g_selfloop && d_a_dst, SGS_EINVAL, "sgs_gat_alpha_bwd: null pointer");
+    hipLaunchKernelGGL(gat_alpha_bwd, dim3(cdiv(N * 64, kT)), dim3(kT), 0, stream, a_src, a_dst, N, in_ptr, in_src, in_eid,
+                       negative_slope, 1.0f / (1.0f - p_drop), dropout_thresh(p_drop), p_drop > 0.f ? 1 : 0, seed, site, soft_in,
+                       soft_loop, galpha, gloop, g_edge, g_selfloop, d_a_dst);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_gather_by_eid(const float* by_eid, const int32_t* eid, int64_t n, float* out_order, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(n >= 0, SGS_EINVAL, "sgs_gather_by_eid: bad size");
+    if (n == 0) return SGS_OK;
+    SGS_REQUIRE(by_eid && eid && out_order, SGS_EINVAL, "sgs_gather_by_eid: null pointer");
+    hipLaunchKernelGGL(gather_by_eid, dim3(cdiv(n, kT)), dim3(kT), 0, stream, by_eid, eid, n, out_order);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_scatter_by_eid(const float* in_order, const int32_t* eid, int64_t n, float* by_eid, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(n >= 0, SGS_EINVAL, "sgs_scatter_by_eid: bad size");
+    if (n == 0) return SGS_OK;
+    SGS_REQUIRE(in_order && eid && by_eid, SGS_EINVAL, "sgs_scatter_by_eid: null pointer");
+    hipLaunchKernelGGL(scatter_by_eid, dim3(cdiv(n, kT)), dim3(kT), 0, stream, in_order, eid, n, by_eid);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+}  // extern "C"

@@ -79,3 +79,73 @@ class GNNModel(nn.Module):
         act = ops.ACT_RELU_DROPOUT if p > 0 else ops.ACT_RELU
         h = self.gcn1(x, edge_index, norm=norm, act=act, p=p, seed=_DropoutClock.next_seed(), site=SITE_GNN)
         return self.gcn2(h, edge_index, norm=norm)
+
+
+# ------------------------------------------------------------------ GAT head (model.py:189-208)
+SITE_GAT_ATT, SITE_GAT_ACT = 16, 32          # attention dropout uses site, site + 1 per layer
+
+
+class GATConv(nn.Module):
+    """PyG 2.3.1 GATConv with heads = 1 as torch_geometric.nn.models.GAT instantiates it: parameters
+    `lin_src.weight` (shared with `lin_dst.weight`), `att_src`, `att_dst` [1,1,out], `bias` [out]."""
+
+    def __init__(self, in_channels, out_channels, heads=1, concat=True, negative_slope=0.2, dropout=0.0):
+        super().__init__()
+        if heads != 1:
+            raise NotImplementedError("the reference's GATModel never passes `heads` on to GAT: heads = 1")
+        self.in_channels, self.out_channels, self.negative_slope, self.dropout = in_channels, out_channels, negative_slope, dropout
+        self.lin_src = nn.Linear(in_channels, out_channels, bias=False)
+        self.lin_dst = self.lin_src
+        self.att_src = nn.Parameter(torch.empty(1, 1, out_channels))
+        self.att_dst = nn.Parameter(torch.empty(1, 1, out_channels))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        a = math.sqrt(6.0 / (in_channels + out_channels))
+        nn.init.uniform_(self.lin_src.weight, -a, a)
+        b = math.sqrt(6.0 / (1 + out_channels))
+        nn.init.uniform_(self.att_src, -b, b)
+        nn.init.uniform_(self.att_dst, -b, b)
+
+    def forward(self, x, edge_index, *, act=ops.ACT_NONE, p_act=0.0, seed=0, layer=0):
+        graph = ops.get_graph(edge_index, x.shape[0])
+        xl = self.lin_src(x)
+        a_s = xl @ self.att_src.reshape(-1)          # node-level dots (library GEMV)
+        a_d = xl @ self.att_dst.reshape(-1)
+        p_att = self.dropout if self.training else 0.0
+        return ops.gat_aggregate(xl, a_s, a_d, self.bias, graph, self.negative_slope, p_att, seed, SITE_GAT_ATT + 2 * layer, act,
+                                 p_act, seed, SITE_GAT_ACT + layer)
+
+
+class GAT(nn.Module):
+    """torch_geometric.nn.models.GAT(in, hidden, num_layers=2, out_channels, dropout, act='relu')."""
+    supports_edge_weight = False
+
+    def __init__(self, in_channels, hidden_channels, num_layers, out_channels, dropout=0.0, act='relu'):
+        super().__init__()
+        if num_layers != 2 or act != 'relu':
+            raise NotImplementedError
+        self.dropout = dropout
+        self.convs = nn.ModuleList([GATConv(in_channels, hidden_channels, dropout=dropout),
+                                    GATConv(hidden_channels, out_channels, concat=False, dropout=dropout)])
+
+    def forward(self, x, edge_index, edge_weight=None):
+        # edge_weight is dropped, exactly as PyG's BasicGNN does for a conv without edge-weight support
+        p = self.dropout if self.training else 0.0
+        act = ops.ACT_RELU_DROPOUT if p > 0 else ops.ACT_RELU
+        seed = _DropoutClock.next_seed()
+        h = self.convs[0](x, edge_index, act=act, p_act=p, seed=seed, layer=0)
+        return self.convs[1](h, edge_index, seed=seed, layer=1)
+
+
+class GATModel(nn.Module):
+    """model.py:189-208 (`heads` is accepted and unused, as in the reference)."""
+
+    def __init__(self, in_channels, hidden_dim, num_classes, dropout_prob=0.3, heads=8, edge_mlp_type='MLP'):
+        super().__init__()
+        from .scorer import get_edge_mlp
+        self.edge_prob_mlp = get_edge_mlp(in_channels, hidden_dim, dropout_prob, edge_mlp_type)
+        self.dropout_prob = dropout_prob
+        self.GAT = GAT(in_channels=in_channels, hidden_channels=hidden_dim, num_layers=2, out_channels=num_classes,
+                       dropout=dropout_prob, act='relu')
+
+    def forward(self, data, edge_index, edge_weight=None):
+        return self.GAT(data.x, edge_index, edge_weight=edge_weight)

@@ -481,3 +481,68 @@ def edge_regularizers(w, logits, sampled_edge_index, y, train_mask, coef1, coef2
     total = _EdgeReg.apply(w.contiguous(), logits.contiguous(), sampled_edge_index.contiguous(), y.contiguous(),
                            _u8(train_mask), graph, float(coef1), float(coef2), box)
     return total, box[0]
+
+
+# ------------------------------------------------------------------ GAT attention (K8)
+class _GATAggregate(torch.autograd.Function):
+    """out = act( sum_k alpha_k x'[src_k] + alpha_loop x'[i] + bias ), alpha = dropout(softmax(leaky_relu(a_s+a_d)))."""
+
+    @staticmethod
+    def forward(ctx, xl, a_s, a_d, bias, graph, slope, p_att, seed_att, site_att, act, p_act, seed_act, site_act):
+        L = _lib.lib()
+        N, D = xl.shape
+        n = graph.n_edges
+        dev = xl.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        soft_in, alpha_in = torch.empty(max(n, 1), **f32), torch.empty(max(n, 1), **f32)
+        soft_loop, alpha_loop = torch.empty(N, **f32), torch.empty(N, **f32)
+        _lib.check(L.sgs_gat_alpha_fwd(_ptr(a_s), _ptr(a_d), N, n, _ptr(graph.in_ptr), _ptr(graph.in_src), _ptr(graph.in_eid),
+                                       float(slope), float(p_att), seed_att, site_att, _ptr(soft_in), _ptr(soft_loop),
+                                       _ptr(alpha_in), _ptr(alpha_loop), _stream()), "sgs_gat_alpha_fwd")
+        Y = _spmm(xl, graph.in_ptr, graph.in_src, alpha_in, alpha_loop, bias, act, p_act, seed_act, site_act, N, D, n)
+        ctx.save_for_backward(xl, a_s, a_d, soft_in, soft_loop, alpha_in, alpha_loop, Y if act != ACT_NONE else None)
+        ctx.graph, ctx.slope, ctx.p_att, ctx.seed_att, ctx.site_att = graph, float(slope), float(p_att), seed_att, site_att
+        ctx.act, ctx.p_act, ctx.has_bias = act, float(p_act), bias is not None
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        L = _lib.lib()
+        xl, a_s, a_d, soft_in, soft_loop, alpha_in, alpha_loop, Y = ctx.saved_tensors
+        gr = ctx.graph
+        N, D = xl.shape
+        n = gr.n_edges
+        dev = xl.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        dY = dY.contiguous()
+        if ctx.act != ACT_NONE:
+            dZ = torch.empty_like(dY)
+            _lib.check(L.sgs_act_bwd(_ptr(dY), _ptr(Y), dY.numel(), ctx.act, ctx.p_act, _ptr(dZ), _stream()), "sgs_act_bwd")
+        else:
+            dZ = dY
+        dbias = _colsum(dZ) if ctx.has_bias else None
+        # alpha re-ordered into src-CSR entry order for the transposed aggregation
+        by_eid = torch.empty(max(n, 1), **f32)
+        alpha_out = torch.empty(max(n, 1), **f32)
+        _lib.check(L.sgs_scatter_by_eid(_ptr(alpha_in), _ptr(gr.in_eid), n, _ptr(by_eid), _stream()), "sgs_scatter_by_eid")
+        _lib.check(L.sgs_gather_by_eid(_ptr(by_eid), _ptr(gr.out_eid), n, _ptr(alpha_out), _stream()), "sgs_gather_by_eid")
+        dxl = _spmm(dZ, gr.out_ptr, gr.out_dst, alpha_out, alpha_loop, None, ACT_NONE, 0.0, 0, 0, N, D, n)
+        galpha, gloop = torch.empty(max(n, 1), **f32), torch.empty(N, **f32)
+        _lib.check(L.sgs_sddmm_csr(_ptr(dZ), _ptr(xl), N, D, n, _ptr(gr.in_ptr), _ptr(gr.in_src), _ptr(gr.in_eid), _ptr(galpha),
+                                   _ptr(gloop), _stream()), "sgs_sddmm_csr")
+        g_edge, g_self, d_ad = torch.empty(max(n, 1), **f32), torch.empty(N, **f32), torch.empty(N, **f32)
+        _lib.check(L.sgs_gat_alpha_bwd(_ptr(a_s), _ptr(a_d), N, n, _ptr(gr.in_ptr), _ptr(gr.in_src), _ptr(gr.in_eid), ctx.slope,
+                                       ctx.p_att, ctx.seed_att, ctx.site_att, _ptr(soft_in), _ptr(soft_loop), _ptr(galpha),
+                                       _ptr(gloop), _ptr(g_edge), _ptr(g_self), _ptr(d_ad), _stream()), "sgs_gat_alpha_bwd")
+        g_out = torch.empty(max(n, 1), **f32)
+        _lib.check(L.sgs_gather_by_eid(_ptr(g_edge), _ptr(gr.out_eid), n, _ptr(g_out), _stream()), "sgs_gather_by_eid")
+        ones = torch.ones(N, 1, **f32)
+        d_as = _spmm(ones, gr.out_ptr, gr.out_dst, g_out, g_self, None, ACT_NONE, 0.0, 0, 0, N, 1, n).reshape(N)
+        return dxl, d_as, d_ad, dbias, None, None, None, None, None, None, None, None, None
+
+
+def gat_aggregate(xl, a_s, a_d, bias, graph: Graph, negative_slope=0.2, p_att=0.0, seed_att=0, site_att=0, act=ACT_NONE,
+                  p_act=0.0, seed_act=0, site_act=0):
+    _need_gpu(xl, a_s, a_d, bias)
+    return _GATAggregate.apply(xl.contiguous(), a_s.contiguous(), a_d.contiguous(), bias, graph, float(negative_slope),
+                               float(p_att), int(seed_att), int(site_att), act, float(p_act), int(seed_act), int(site_act))
