@@ -7,5 +7,6 @@ from .model import GCNConv, GNNModel, GATConv, GAT, GATModel, set_dropout_seed  
 from .scorer import EdgeProbGCN, EdgeProbMLP, EdgeProbSAGE, get_edge_mlp  # noqa: F401
 from .sampling import gumbel_softmax_sampling, random_edge_sampling, manual_seed  # noqa: F401
 from .training import train, train_hybrid, train_straight_through, train_two_pass  # noqa: F401
+from .evaluate import evaluate, ensemble_evaluate  # noqa: F401
 from .utils import calculate_f1, consistency_loss, fix_seeds  # noqa: F401
 from .data import Batch, degree_prior, synthetic_graph, reddit_partition_stream  # noqa: F401

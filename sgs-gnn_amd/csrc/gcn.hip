@@ -67,6 +67,68 @@ __global__ void __launch_bounds__(kT) fill_rows(const int64_t* __restrict__ ei, 
     tmp_out[atomicAdd(&cur_out[s], 1)] = static_cast<int>(e);
 }
 
+// Small-N variants (N <= kLdsNodes, e.g. METIS partitions): every edge hammering ~1k global counters
+// is contention-bound, so a workgroup first counts / ranks its chunk of edges in LDS and touches each
+// global counter at most once per chunk.
+constexpr int kLdsNodes = 4096;
+constexpr int kEdgesPerBlock = 4096;      // 16 per thread
+__global__ void __launch_bounds__(kT) count_degrees_lds(const int64_t* __restrict__ ei, int64_t n_edges, int N, int* __restrict__ cnt_in,
+                                                       int* __restrict__ cnt_out, int* __restrict__ loop_eid) {
+    __shared__ int lin[kLdsNodes], lout[kLdsNodes];
+    for (int i = threadIdx.x; i < N; i += kT) { lin[i] = 0; lout[i] = 0; }
+    __syncthreads();
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * kEdgesPerBlock;
+    for (int it = 0; it < kEdgesPerBlock / kT; ++it) {
+        const int64_t e = base + it * kT + threadIdx.x;
+        if (e < n_edges) {
+            const int s = static_cast<int>(ei[e]), d = static_cast<int>(ei[n_edges + e]);
+            atomicAdd(&lin[d], 1);
+            atomicAdd(&lout[s], 1);
+            if (s == d) atomicMax(&loop_eid[s], static_cast<int>(e));
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += kT) {
+        if (lin[i]) atomicAdd(&cnt_in[i], lin[i]);
+        if (lout[i]) atomicAdd(&cnt_out[i], lout[i]);
+    }
+}
+
+__global__ void __launch_bounds__(kT) fill_rows_lds(const int64_t* __restrict__ ei, int64_t n_edges, int N, int* __restrict__ cur_in,
+                                                   int* __restrict__ cur_out, int* __restrict__ tmp_in, int* __restrict__ tmp_out) {
+    __shared__ int lin[kLdsNodes], lout[kLdsNodes];
+    for (int i = threadIdx.x; i < N; i += kT) { lin[i] = 0; lout[i] = 0; }
+    __syncthreads();
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * kEdgesPerBlock;
+    int rs[kEdgesPerBlock / kT], rd[kEdgesPerBlock / kT], ss[kEdgesPerBlock / kT], dd[kEdgesPerBlock / kT];
+#pragma unroll
+    for (int it = 0; it < kEdgesPerBlock / kT; ++it) {
+        const int64_t e = base + it * kT + threadIdx.x;
+        ss[it] = -1;
+        if (e < n_edges) {
+            ss[it] = static_cast<int>(ei[e]);
+            dd[it] = static_cast<int>(ei[n_edges + e]);
+            rd[it] = atomicAdd(&lin[dd[it]], 1);      // rank inside this chunk
+            rs[it] = atomicAdd(&lout[ss[it]], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += kT) {       // reserve this chunk's slots: one global atomic per touched node
+        const int ci = lin[i], co = lout[i];
+        lin[i] = ci ? atomicAdd(&cur_in[i], ci) : 0;
+        lout[i] = co ? atomicAdd(&cur_out[i], co) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kEdgesPerBlock / kT; ++it) {
+        if (ss[it] >= 0) {
+            const int e = static_cast<int>(base + it * kT + threadIdx.x);
+            tmp_in[lin[dd[it]] + rd[it]] = e;
+            tmp_out[lout[ss[it]] + rs[it]] = e;
+        }
+    }
+}
+
 // The atomic fill leaves each row's edge ids in arrival order; sorting them (unique ints) makes
 // the CSR -- and every floating-point sum over a row -- deterministic.
 // Rows of <= 64 entries: one wave, bitonic network through lane shuffles.
@@ -562,13 +624,23 @@ int sgs_graph_build(const int64_t* edge_index, int64_t n_edges, int64_t N, int32
     int* tmp_out = cv.take<int>(n_edges + 1);
     SGS_HIP_OK(hipMemsetAsync(cnt_in, 0, 2 * carve_bytes(N + 1, 4), stream));      // cnt_in + cnt_out are adjacent
     SGS_HIP_OK(hipMemsetAsync(loop_eid, 0xff, static_cast<size_t>(N) * 4, stream));  // -1
-    if (n_edges > 0)
-        hipLaunchKernelGGL(count_degrees, dim3(cdiv(n_edges, kT)), dim3(kT), 0, stream, edge_index, n_edges, cnt_in, cnt_out,
-                           loop_eid);
+    const bool small_n = N <= kLdsNodes;
+    if (n_edges > 0) {
+        if (small_n)
+            hipLaunchKernelGGL(count_degrees_lds, dim3(cdiv(n_edges, kEdgesPerBlock)), dim3(kT), 0, stream, edge_index, n_edges,
+                               static_cast<int>(N), cnt_in, cnt_out, loop_eid);
+        else
+            hipLaunchKernelGGL(count_degrees, dim3(cdiv(n_edges, kT)), dim3(kT), 0, stream, edge_index, n_edges, cnt_in, cnt_out,
+                               loop_eid);
+    }
     hipLaunchKernelGGL(scan_counts, dim3(2), dim3(1024), 0, stream, cnt_in, cnt_out, N, in_ptr, out_ptr, cur_in, cur_out);
     if (n_edges > 0) {
-        hipLaunchKernelGGL(fill_rows, dim3(cdiv(n_edges, kT)), dim3(kT), 0, stream, edge_index, n_edges, cur_in, cur_out,
-                           tmp_in, tmp_out);
+        if (small_n)
+            hipLaunchKernelGGL(fill_rows_lds, dim3(cdiv(n_edges, kEdgesPerBlock)), dim3(kT), 0, stream, edge_index, n_edges,
+                               static_cast<int>(N), cur_in, cur_out, tmp_in, tmp_out);
+        else
+            hipLaunchKernelGGL(fill_rows, dim3(cdiv(n_edges, kT)), dim3(kT), 0, stream, edge_index, n_edges, cur_in, cur_out,
+                               tmp_in, tmp_out);
         hipLaunchKernelGGL(sort_rows_wave, dim3(cdiv(2 * N * 64, kT)), dim3(kT), 0, stream, in_ptr, out_ptr, N, tmp_in,
                            tmp_out, edge_index, n_edges, in_eid, in_src, out_eid, out_dst);
         hipLaunchKernelGGL(sort_rows_block, dim3(2 * N), dim3(kT), 0, stream, in_ptr, out_ptr, N, tmp_in, tmp_out, edge_index,
