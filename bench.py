@@ -81,9 +81,19 @@ def kernel_roofline(S, model, batch, reps):
     ms = e0.elapsed_time(e1) / reps
     flops = E * (2.0 * H * H + 2.0 * H)          # algorithmic flops per launch after the W1 split
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "edge_score_kernel<8,false> (sgs_edge_score_fwd)", "achieved": round(achieved, 3),
+    # HBM bytes per launch come from the separate rocprofv3 --pmc passes on this very kernel and shape
+    # (profiles/r01_scorer_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction applied); null if the
+    # resident shape differs from the profiled one.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_scorer_pmc.json")))
+        if f"E={E}," in pmc["kernel"]:
+            traffic = pmc["hbm_traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return {"bound": "mfma", "kernel": "edge_score_kernel<8,false,false> (sgs_edge_score_fwd)", "achieved": round(achieved, 3),
             "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": None, "edges_per_launch": E, "ms_per_launch": round(ms, 4),
+            "traffic": traffic, "edges_per_launch": E, "ms_per_launch": round(ms, 4),
             "flops_per_edge": 2 * H * H + 2 * H}
 
 
