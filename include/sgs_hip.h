@@ -270,6 +270,16 @@ int sgs_gat_alpha_bwd(const float* a_src, const float* a_dst, int64_t N, int64_t
 int sgs_gather_by_eid(const float* by_eid, const int32_t* eid, int64_t n, float* out_order, sgs_stream_t stream);
 int sgs_scatter_by_eid(const float* in_order, const int32_t* eid, int64_t n, float* by_eid, sgs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Weight-gradient GEMM of the node-level Linear layers: C[M,N] = A^T B, A [K,M], B [K,N] row-major,
+ * K = number of graph nodes (dW = dY^T X for GCNConv.lin, model.py:94-95,151-153).  fp32 MFMA fed from
+ * coalesced global reads, split-K with a fixed-order combine (deterministic).  Skinny shapes only (the
+ * vendor GEMM serves the rest): meant for M, N <= ~1k.
+ * ---------------------------------------------------------------------------------- */
+size_t sgs_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N);
+int sgs_gemm_tn(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, void* ws, size_t ws_bytes,
+                sgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

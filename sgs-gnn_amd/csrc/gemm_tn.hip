@@ -1,0 +1,100 @@
+// Weight-gradient GEMM  C[M,N] = A^T B  with A [K,M], B [K,N] row-major (K = number of graph nodes):
+// dW = dY^T X of every node-level Linear on the path (model.py:94-95,151-153 GCNConv.lin, fc layers).
+// The vendor library picks a 256x256 macro-tile for these skinny shapes (M = 256, N = 602, K = 1013 ->
+// 3 workgroups, 233 us); here one wave owns a 32x32 output tile and a K-slice and feeds
+// v_mfma_f32_32x32x2_f32 straight from global memory: the reduction index is the ROW index of both
+// operands, so the A and B operand of lane l (row k + (l >> 5), column l & 31) are coalesced 128-B reads
+// and no LDS / transpose is needed.  Split-K partial tiles are combined in a fixed order (deterministic).
+#include "sgs_common.h"
+
+namespace sgs {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int kUnroll = 8;
+
+__global__ void __launch_bounds__(64) gemm_tn_tile(const float* __restrict__ A, const float* __restrict__ B, int64_t K, int M, int N,
+                                                  int ksplit, float* __restrict__ slab) {
+    const int lane = threadIdx.x, kh = lane >> 5, l31 = lane & 31;
+    const int ti = blockIdx.x, tj = blockIdx.y, s = blockIdx.z;
+    const int i = ti * 32 + l31, j = tj * 32 + l31;
+    const bool iok = i < M, jok = j < N;
+    const int64_t per = ((K + ksplit - 1) / ksplit + 1) & ~int64_t(1);      // even slice length
+    const int64_t k0 = s * per, k1 = (k0 + per < K) ? k0 + per : K;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    int64_t k = k0;
+    for (; k + 2 * kUnroll <= k1; k += 2 * kUnroll) {
+        float a[kUnroll], b[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t kk = k + 2 * u + kh;
+            a[u] = iok ? A[kk * M + i] : 0.f;
+            b[u] = jok ? B[kk * N + j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    }
+    for (; k < k1; k += 2) {
+        const int64_t kk = k + kh;
+        const float a = (iok && kk < k1) ? A[kk * M + i] : 0.f;
+        const float b = (jok && kk < k1) ? B[kk * N + j] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    float* out = slab + static_cast<int64_t>(s) * M * N;
+    if (jok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (row < M) out[static_cast<int64_t>(row) * N + j] = acc[r];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) gemm_tn_reduce(const float* __restrict__ slab, int64_t mn, int ksplit, float* __restrict__ C) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= mn) return;
+    float acc = 0.f;
+    for (int s = 0; s < ksplit; ++s) acc += slab[static_cast<int64_t>(s) * mn + i];
+    C[i] = acc;
+}
+
+inline int pick_ksplit(int64_t K, int64_t M, int64_t N) {
+    const int64_t tiles = cdiv(M, 32) * cdiv(N, 32);
+    int ks = 1;
+    while (ks < 64 && tiles * ks < 1024 && K / (ks * 2) >= 64) ks *= 2;      // fill ~1024 SIMDs, keep >= 64 rows per slice
+    return ks;
+}
+
+}  // namespace
+}  // namespace sgs
+
+using namespace sgs;
+
+extern "C" {
+
+size_t sgs_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N) {
+    if (K < 0 || M < 0 || N < 0) return 256;
+    return carve_bytes(static_cast<size_t>(pick_ksplit(K, M, N)) * M * N, 4) + 256;
+}
+
+int sgs_gemm_tn(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, void* ws, size_t ws_bytes,
+                sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(K >= 0 && M >= 0 && N >= 0 && M < (1 << 30) && N < (1 << 30), SGS_EINVAL, "sgs_gemm_tn: bad sizes");
+    if (M == 0 || N == 0) return SGS_OK;
+    SGS_REQUIRE(C && (K == 0 || (A && B)), SGS_EINVAL, "sgs_gemm_tn: null pointer");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_gemm_tn_workspace_bytes(K, M, N), SGS_EWORKSPACE, "sgs_gemm_tn: workspace too small");
+    const int ks = pick_ksplit(K, M, N);
+    Carver cv(ws);
+    float* slab = cv.take<float>(static_cast<size_t>(ks) * M * N);
+    float* dst = ks == 1 ? C : slab;
+    hipLaunchKernelGGL(gemm_tn_tile, dim3(cdiv(M, 32), cdiv(N, 32), ks), dim3(64), 0, stream, A, B, K, static_cast<int>(M),
+                       static_cast<int>(N), ks, dst);
+    if (ks > 1) hipLaunchKernelGGL(gemm_tn_reduce, dim3(cdiv(M * N, 256)), dim3(256), 0, stream, slab, M * N, ks, C);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+}  // extern "C"

@@ -55,10 +55,26 @@ class GCNConv(nn.Module):
         nn.init.uniform_(self.lin.weight, -a, a)
         nn.init.zeros_(self.bias)
 
+    def _lin(self, x):
+        """x W^T, memoised on (x, W) identity + version: the hybrid step runs GNNModel twice on the same
+        batch.x with the same weights (learned and random forward, training_hybrid.py:88,93)."""
+        W = self.lin.weight
+        key = (x.data_ptr(), x._version, tuple(x.shape), W.data_ptr(), W._version, torch.is_grad_enabled())
+        c = getattr(self, "_lin_cache", None)
+        if c is not None and c[0] == key and c[1]() is x:
+            return c[2]
+        xl = ops.linear_nobias(x, W)
+        import weakref
+        try:
+            self._lin_cache = (key, weakref.ref(x), xl)
+        except TypeError:
+            self._lin_cache = None
+        return xl
+
     def forward(self, x, edge_index, edge_weight=None, *, norm=None, act=ops.ACT_NONE, p=0.0, seed=0, site=0):
         if norm is None:
             norm = ops.gcn_norm(ops.get_graph(edge_index, x.shape[0]), edge_weight)
-        return ops.gcn_propagate(self.lin(x), norm, self.bias, act=act, p=p, seed=seed, site=site)
+        return ops.gcn_propagate(self._lin(x), norm, self.bias, act=act, p=p, seed=seed, site=site)
 
 
 class GNNModel(nn.Module):

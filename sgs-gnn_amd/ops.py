@@ -546,3 +546,34 @@ def gat_aggregate(xl, a_s, a_d, bias, graph: Graph, negative_slope=0.2, p_att=0.
     _need_gpu(xl, a_s, a_d, bias)
     return _GATAggregate.apply(xl.contiguous(), a_s.contiguous(), a_d.contiguous(), bias, graph, float(negative_slope),
                                float(p_att), int(seed_att), int(site_att), act, float(p_act), int(seed_act), int(site_act))
+
+
+# ------------------------------------------------------------------ node-level Linear with a hand-written weight gradient
+class _LinearNoBias(torch.autograd.Function):
+    """y = x W^T (library GEMM); dW = dY^T x on the f32 matrix cores (sgs_gemm_tn); dx = dY W (library)."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        ctx.save_for_backward(x, W)
+        return x @ W.t()
+
+    @staticmethod
+    def backward(ctx, dY):
+        L = _lib.lib()
+        x, W = ctx.saved_tensors
+        dx = dW = None
+        dY = dY.contiguous()
+        if ctx.needs_input_grad[0]:
+            dx = dY @ W
+        if ctx.needs_input_grad[1]:
+            K, M, N = x.shape[0], W.shape[0], W.shape[1]
+            dW = torch.empty(M, N, dtype=torch.float32, device=x.device)
+            ws = workspace(L.sgs_gemm_tn_workspace_bytes(K, M, N), x.device)
+            _lib.check(L.sgs_gemm_tn(_ptr(dY, torch.float32), _ptr(x.contiguous(), torch.float32), K, M, N, _ptr(dW), ws.data_ptr(),
+                                     ws.numel(), _stream()), "sgs_gemm_tn")
+        return dx, dW
+
+
+def linear_nobias(x, W):
+    _need_gpu(x, W)
+    return _LinearNoBias.apply(x, W)

@@ -142,3 +142,22 @@ def test_propagate_is_run_to_run_deterministic(pkg):
         nm = pkg.ops.gcn_norm(gr, w)
         outs.append(pkg.ops.gcn_propagate(X, nm))
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("K,M,N", [(1013, 256, 602), (1013, 41, 256), (7, 5, 3), (2000, 256, 256), (333, 70, 8710), (64, 32, 32), (1, 4, 4)])
+def test_gemm_tn_weight_gradient(pkg, K, M, N):
+    """dW = dY^T X on the f32 matrix cores vs fp64."""
+    g = torch.Generator().manual_seed(K + M + N)
+    dY = torch.randn(K, M, generator=g)
+    X = torch.randn(K, N, generator=g)
+    W = torch.randn(M, N, generator=g).to(DEV).requires_grad_(True)
+    xd = X.to(DEV).requires_grad_(True)
+    y = pkg.ops.linear_nobias(xd, W)
+    refy = X.double() @ W.detach().cpu().double().t()
+    assert float((y.detach().cpu().double() - refy).abs().max()) / (float(refy.abs().max()) + 1e-12) < 1e-5
+    y.backward(dY.to(DEV))
+    ref = dY.double().t() @ X.double()
+    err = float((W.grad.cpu().double() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+    assert err < 2e-6, err
+    refx = dY.double() @ W.detach().cpu().double()
+    assert float((xd.grad.cpu().double() - refx).abs().max()) / (float(refx.abs().max()) + 1e-12) < 1e-5
