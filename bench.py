@@ -62,7 +62,7 @@ def kernel_roofline(S, model, batch, reps):
     L = S._lib.lib()
     U = (codes @ sc.fc1.weight[:, H:].t()).contiguous()
     out = torch.empty(E, dtype=torch.float32, device=codes.device)
-    ws = ops.workspace(L.sgs_edge_score_workspace_bytes(H), codes.device)
+    ws = ops.workspace(L.sgs_edge_score_workspace_bytes(N_NODES, H), codes.device)
     W1, b1, w2, b2 = sc.fc1.weight.detach().contiguous(), sc.fc1.bias.detach(), sc.fc2.weight.detach().reshape(-1).contiguous(), sc.fc2.bias.detach()
 
     def launch():
@@ -199,7 +199,13 @@ def main():
 
     if rank == 0:
         big = max(pool, key=lambda b: b.edge_index.shape[1])
-        roof = kernel_roofline(S, model, big, reps=20)
+        L = S._lib.lib()
+        L.sgs_edge_score_set_variant(0)                      # in-process A/B of the two scorer forward kernels
+        roof_tiled = kernel_roofline(S, model, big, reps=20)
+        L.sgs_edge_score_set_variant(1)
+        roof = kernel_roofline(S, model, big, reps=20)       # the default (used by the timed steps above)
+        roof["kernel"] = "edge_score_stream_kernel<8> (sgs_edge_score_fwd, register-streaming variant)"
+        roof["alt_lds_tiled_variant"] = {"achieved": roof_tiled["achieved"], "ms_per_launch": roof_tiled["ms_per_launch"]}
         rec = {
             "metric": "sampled edges/sec + training steps/sec, Reddit hybrid 20% sparsity",
             "value": round(sampled_all / dt_all, 1), "unit": "sampled edges/s",

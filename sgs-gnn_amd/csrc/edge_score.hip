@@ -266,6 +266,137 @@ __global__ void __launch_bounds__(kT, 3) edge_score_kernel(ScoreArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Forward variant B ("stream"): no LDS tiles, no per-k-step barriers.  Both MFMA operands are streamed
+// from L2 straight into registers:
+//   * W1a is pre-packed as Wp[tile t][j4][lane][4]: the A operands of lane (l31, kh) for the four
+//     k2-steps j = 4 j4 .. 4 j4 + 3 of tile t (k = 8 j4 + 2 jj + kh, h = 32 t + l31) are ONE 16-byte load;
+//   * the node codes are re-laid as Ceo[n][kh][H/2] (even / odd k split) so that the B operands of lane
+//     (edge l31, kh) for the same four k2-steps are one 16-byte load of x and one of y.
+// Waves never wait for each other until the final fc2 combine, so three waves per SIMD keep the matrix
+// pipe fed while others gather; operand registers are double-buffered one j4-iteration (4 NTW MFMAs) ahead.
+// Requires H % 64 == 0 (H = 64, 128, 256); other sizes use the LDS-tiled kernel above.
+__global__ void __launch_bounds__(kT) pack_w1a_stream(const float* __restrict__ W1, int H, float* __restrict__ Wp) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;     // one output float
+    if (i >= static_cast<int64_t>(H) * H) return;
+    const int jj = i & 3, lane = (i >> 2) & 63;
+    const int64_t rest = i >> 8;                  // t * (H/8) + j4
+    const int j4 = static_cast<int>(rest % (H / 8)), t = static_cast<int>(rest / (H / 8));
+    const int kh = lane >> 5, l31 = lane & 31;
+    const int k = 8 * j4 + 2 * jj + kh, h = 32 * t + l31;
+    Wp[i] = W1[static_cast<int64_t>(h) * 2 * H + k];
+}
+__global__ void __launch_bounds__(kT) pack_codes_eo(const float* __restrict__ codes, int64_t N, int H, float* __restrict__ Ceo) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (i >= N * H) return;
+    const int64_t n = i / H;
+    const int k = static_cast<int>(i - n * H);
+    Ceo[n * H + (k & 1) * (H / 2) + (k >> 1)] = codes[i];
+}
+
+template <int NT>
+__global__ void __launch_bounds__(kT, 3) edge_score_stream_kernel(ScoreArgs a, const float* __restrict__ Wp, const float* __restrict__ Ceo) {
+    constexpr int H = 32 * NT;
+    constexpr int NTW = NT / 2;
+    constexpr int NJ4 = H / 8;
+    __shared__ float zpart[2][kBM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int eg = wave & 1, hh = wave >> 1;
+    const int kh = lane >> 5, l31 = lane & 31;
+    const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kBM;
+    const int el = 32 * eg + l31;
+    const int64_t r = row0 + el;
+    const bool live = r < a.n;
+    int s = 0, d = 0;
+    int64_t eg_id = 0;
+    if (live) {
+        eg_id = a.active ? a.active[r] : r;
+        s = static_cast<int>(a.src[eg_id]);
+        d = static_cast<int>(a.dst[eg_id]);
+    }
+    const float4* xp = reinterpret_cast<const float4*>(Ceo + static_cast<int64_t>(s) * H + kh * (H / 2));
+    const float4* yp = reinterpret_cast<const float4*>(Ceo + static_cast<int64_t>(d) * H + kh * (H / 2));
+    const float4* wp = reinterpret_cast<const float4*>(Wp) + (static_cast<int64_t>(hh) * NTW * NJ4) * 64 + lane;
+
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+    float4 A0[NTW], A1[NTW], x0, y0, x1, y1;
+    auto load = [&](int j4, float4 (&A)[NTW], float4& x, float4& y) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) A[t] = wp[(static_cast<int64_t>(t) * NJ4 + j4) * 64];
+        x = xp[j4];
+        y = yp[j4];
+    };
+    auto mma = [&](const float4 (&A)[NTW], const float4& x, const float4& y) {
+        const float b[4] = {x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const float av = jj == 0 ? A[t].x : jj == 1 ? A[t].y : jj == 2 ? A[t].z : A[t].w;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[jj], acc[t], 0, 0, 0);
+            }
+        }
+    };
+    load(0, A0, x0, y0);
+#pragma unroll 1
+    for (int j4 = 0; j4 < NJ4; j4 += 2) {
+        load(j4 + 1, A1, x1, y1);                    // NJ4 is even (H % 16 == 0)
+        mma(A0, x0, y0);
+        if (j4 + 2 < NJ4) load(j4 + 2, A0, x0, y0);
+        mma(A1, x1, y1);
+    }
+
+    // ---- epilogue (same as the tiled kernel): hidden unit hh*H/2 + 32t + (q&3) + 8(q>>2) + 4kh
+    const int Hrt = a.H;
+    const uint32_t rkey = dropout_row_key(a.seed, a.site, static_cast<uint64_t>(eg_id));
+    const float* Us = a.U + static_cast<int64_t>(s) * H;
+    const float* Ud = a.U + static_cast<int64_t>(d) * H;
+    float z = 0.f;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int hb = hh * (H / 2) + 32 * t + 8 * g + 4 * kh;
+            if (hb < Hrt) {      // always true; the runtime bound keeps hipcc from hoisting all 64 float4 loads at once
+                const float4 us = *reinterpret_cast<const float4*>(Us + hb);
+                const float4 ud = *reinterpret_cast<const float4*>(Ud + hb);
+                const float4 bb = *reinterpret_cast<const float4*>(a.b1 + hb);
+                const float4 ww = *reinterpret_cast<const float4*>(a.w2 + hb);
+                const float u4[4] = {us.x - ud.x, us.y - ud.y, us.z - ud.z, us.w - ud.w};
+                const float b4[4] = {bb.x, bb.y, bb.z, bb.w};
+                const float w4[4] = {ww.x, ww.y, ww.z, ww.w};
+                uint32_t bits[2] = {0u, 0u};
+                if (a.use_drop) {
+                    bits[0] = dropout_pair_bits(rkey, static_cast<uint32_t>(hb >> 1));
+                    bits[1] = dropout_pair_bits(rkey, static_cast<uint32_t>((hb >> 1) + 1));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = (acc[t][4 * g + j] + u4[j]) + b4[j];
+                    float m = v > 0.f ? 1.f : 0.f;
+                    if (a.use_drop) {
+                        const uint32_t draw = (j & 1) ? (bits[j >> 1] >> 16) : (bits[j >> 1] & 0xFFFFu);
+                        m = draw >= a.drop_thresh ? m * a.drop_scale : 0.f;
+                    }
+                    z = fmaf(w4[j], v * m, z);
+                }
+            }
+        }
+    }
+    z += __shfl_xor(z, 32, 64);
+    if (kh == 0) zpart[hh][el] = z;
+    __syncthreads();
+    if (live && hh == 0 && kh == 0) {
+        const float zz = (zpart[0][el] + zpart[1][el]) + a.b2[0];
+        a.p_out[r] = 1.0f / (1.0f + expf(-zz));
+    }
+}
+
 // out[v,:] = sum_{k in out-row v} sgn_out * Mo[out_eid[k],:] (* T[out_dst[k],:])
 //          + sum_{k in in-row v}  sgn_in  * Mi[in_eid[k],:]  (* T[in_src[k],:])
 // Scatter of per-edge gradient rows to both endpoints as a deterministic gather over the two
@@ -415,7 +546,15 @@ using namespace sgs;
 
 extern "C" {
 
-size_t sgs_edge_score_workspace_bytes(int64_t H) { return carve_bytes(static_cast<size_t>(H < 0 ? 0 : H) * H, 4) + 256; }
+size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H) {
+    if (N < 0) N = 0;
+    if (H < 0) H = 0;
+    return carve_bytes(static_cast<size_t>(H) * H, 4) + carve_bytes(static_cast<size_t>(N) * H, 4) + 256;
+}
+
+// 0 = LDS-tiled kernel, 1 = register-streaming kernel (forward, H % 64 == 0).  A/B switch for benchmarks.
+static int g_score_variant = 1;
+void sgs_edge_score_set_variant(int v) { g_score_variant = v; }
 
 int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
                        const float* W1, const float* b1, const float* w2, const float* b2, float p_drop, uint64_t seed,
@@ -424,15 +563,26 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
     if (int rc = check_common("sgs_edge_score_fwd", N, H, E, p_drop)) return rc;
     if (E == 0) return SGS_OK;
     SGS_REQUIRE(codes && U && edge_index && W1 && b1 && w2 && b2 && p_out, SGS_EINVAL, "sgs_edge_score_fwd: null pointer");
-    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_workspace_bytes(H), SGS_EWORKSPACE, "sgs_edge_score_fwd: workspace too small");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_workspace_bytes(N, H), SGS_EWORKSPACE, "sgs_edge_score_fwd: workspace too small");
     Carver cv(ws);
     float* WaT = cv.take<float>(static_cast<size_t>(H) * H);
-    hipLaunchKernelGGL(transpose_w1a, dim3(cdiv(H, 32), cdiv(H, 32)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);
+    float* Ceo = cv.take<float>(static_cast<size_t>(N) * H);
     ScoreArgs a{};
     a.codes = codes; a.U = U; a.src = edge_index; a.dst = edge_index + E; a.active = nullptr; a.n = E; a.H = static_cast<int>(H);
     a.WaT = WaT; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.drop_scale = 1.0f / (1.0f - p_drop); a.drop_thresh = dropout_thresh(p_drop); a.seed = seed; a.site = site;
     a.use_drop = p_drop > 0.f; a.p_out = p_out;
+    if (g_score_variant == 1 && H % 64 == 0 && N > 0) {
+        hipLaunchKernelGGL(pack_w1a_stream, dim3(cdiv(H * H, kT)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);
+        hipLaunchKernelGGL(pack_codes_eo, dim3(cdiv(N * H, kT)), dim3(kT), 0, stream, codes, N, static_cast<int>(H), Ceo);
+        const dim3 grid(static_cast<unsigned>(cdiv(E, kBM))), blk(kT);
+        if (H == 256)      hipLaunchKernelGGL((edge_score_stream_kernel<8>), grid, blk, 0, stream, a, WaT, Ceo);
+        else if (H == 128) hipLaunchKernelGGL((edge_score_stream_kernel<4>), grid, blk, 0, stream, a, WaT, Ceo);
+        else               hipLaunchKernelGGL((edge_score_stream_kernel<2>), grid, blk, 0, stream, a, WaT, Ceo);
+        SGS_LAUNCH_OK();
+        return SGS_OK;
+    }
+    hipLaunchKernelGGL(transpose_w1a, dim3(cdiv(H, 32), cdiv(H, 32)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);
     return launch_score<false>(a, stream);
 }
 
@@ -450,7 +600,7 @@ int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64
     if (n_active == 0) return SGS_OK;
     SGS_REQUIRE(codes && U && edge_index && grad_p && W1 && b1 && w2 && b2 && dv && hdz && dz && feat, SGS_EINVAL,
                 "sgs_edge_score_bwd_core: null pointer");
-    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_workspace_bytes(H), SGS_EWORKSPACE, "sgs_edge_score_bwd_core: workspace too small");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_workspace_bytes(N, H), SGS_EWORKSPACE, "sgs_edge_score_bwd_core: workspace too small");
     Carver cv(ws);
     float* WaT = cv.take<float>(static_cast<size_t>(H) * H);
     hipLaunchKernelGGL(transpose_w1a, dim3(cdiv(H, 32), cdiv(H, 32)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);
