@@ -89,6 +89,34 @@ int sgs_sample_topq(int mode, const float* p, const float* prior, double degree_
                     int64_t* sampled_edge_index, float* sampled_p, float* stats, float* keys_out,
                     void* ws, size_t ws_bytes, sgs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Phase API of the sampler for EDGE-SHARDED draws (config 5: one graph, edges split over R ranks in
+ * contiguous shards whose boundaries are multiples of sgs_sampler_chunk()).  Between phases the host
+ * runs the collectives (torch.distributed over RCCL): all-gather of the per-chunk partial sums
+ * (reduced by sgs_sampler_shard_finalize in the single-GPU order => bit-identical normaliser),
+ * all-reduce(sum) of each 2048-bin digit histogram, all-gather of the per-rank (#greater, #equal)
+ * counts.  Noise is keyed by the GLOBAL edge id (edge_offset + local id), ties go to the lowest global
+ * ids, so the selected set is identical for every rank count (tests: 1 vs 2 vs 3 ranks).
+ *   keys buffer: first region of the caller's workspace (sgs_sampler_shard_workspace_bytes), uint32 [E].
+ *   state: 16 bytes of device memory, zeroed by the caller before pass 0.
+ * ---------------------------------------------------------------------------------- */
+size_t sgs_sampler_shard_workspace_bytes(int64_t E_local);
+int64_t sgs_sampler_chunk(void);
+int sgs_sampler_shard_partials(int stage, const float* p, int64_t E, const float* scal, float* part, sgs_stream_t stream);
+int sgs_sampler_shard_finalize(int stage, const float* part_all, int64_t nblk_all, float* scal, sgs_stream_t stream);
+int sgs_sampler_shard_keys(int mode, const float* p, const float* prior, double degree_bias_coef, const float* noise,
+                           uint64_t seed, uint64_t stream_id, int64_t edge_offset, int64_t E, const float* scal,
+                           uint32_t* keys, float* keys_out, uint32_t* hist, sgs_stream_t stream);
+int sgs_sampler_shard_hist(const uint32_t* keys, int64_t E, int pass, const void* state, uint32_t* hist,
+                           sgs_stream_t stream);
+int sgs_sampler_select(uint32_t* hist, int pass, int64_t q, void* state, sgs_stream_t stream);
+int sgs_sampler_shard_count(const uint32_t* keys, int64_t E, const void* state, uint32_t* counts, void* ws,
+                            size_t ws_bytes, sgs_stream_t stream);
+int sgs_sampler_shard_compact(const uint32_t* keys, int64_t E, const void* state, int64_t ties_local, int64_t q_local,
+                              int64_t edge_offset, const float* p, const int64_t* edge_index_local, uint8_t* mask,
+                              int64_t* sampled_eid, int64_t* sampled_edge_index, float* sampled_p, void* ws,
+                              size_t ws_bytes, sgs_stream_t stream);
+
 /* Straight-through weights of sampling.py:137-138,155 for the selected edges:
  *   w_j = clamp(p_e * ((1 - s_e) + s_e), 0, 1),  e = sampled_eid[j]   (forward value)
  * and its exact autograd backward wrt p (s depends on every p through sum(p)):
@@ -131,6 +159,20 @@ int sgs_gcn_norm_fwd(const float* w, int64_t n_edges, int64_t N, const int32_t* 
                      const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
                      const int32_t* loop_eid, float* dis, float* loopw, float* what_in, float* what_out,
                      float* what_loop, sgs_stream_t stream);
+
+/* Edge-sharded gcn_norm (config 5): each rank sums the weights of its own in-edges
+ * (sgs_gcn_degree_partial), the host all-reduces the [N] vector, and sgs_gcn_norm_from_degree continues
+ * with deg_i = 1 + degsum_i (the added self loop counts once; graphs with existing (i,i) edges are not
+ * supported in sharded mode).  sgs_bias_act applies the layer epilogue AFTER the all-reduce of the
+ * partial aggregates:  Y = act(X + bias), act as in sgs_spmm_csr. */
+int sgs_gcn_degree_partial(const float* w, int64_t n_edges, int64_t N, const int32_t* in_ptr, const int32_t* in_src,
+                           const int32_t* in_eid, float* degpart, sgs_stream_t stream);
+int sgs_gcn_norm_from_degree(const float* w, const float* degsum, int64_t n_edges, int64_t N, const int32_t* in_ptr,
+                             const int32_t* in_src, const int32_t* in_eid, const int32_t* out_ptr,
+                             const int32_t* out_dst, const int32_t* out_eid, float* dis, float* loopw, float* what_in,
+                             float* what_out, float* what_loop, sgs_stream_t stream);
+int sgs_bias_act(const float* X, const float* bias, int64_t N, int64_t D, int act, float p_drop, uint64_t seed,
+                 uint32_t site, float* Y, sgs_stream_t stream);
 
 /* gcn_norm backward: from gw_hat[e] = dL/d(what_e) (edge-id order) and gloop[i] = dL/d(what_loop_i)
  * to dL/dw_e, through both the message weight and the degree normalisation:

@@ -22,9 +22,9 @@ def parse_header(path=HEADER):
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"//[^\n]*", "", src)
     protos = {}
-    for m in re.finditer(r"\b(int|size_t|void|const\s+char\s*\*)\s+(sgs_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int64_t|int|size_t|void|const\s+char\s*\*)\s+(sgs_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3)
-        restype = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "void": None}.get(ret.strip(), ctypes.c_char_p)
+        restype = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t, "void": None}.get(ret.strip(), ctypes.c_char_p)
         argtypes, argnames = [], []
         args = " ".join(args.split())
         if args and args != "void":

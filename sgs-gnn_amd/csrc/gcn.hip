@@ -236,6 +236,44 @@ __global__ void __launch_bounds__(kT) norm_deg(const float* __restrict__ w, int6
     if (lane == 0) { dis[i] = di; loopw[i] = lw; }
 }
 
+// Edge-sharded graphs: each rank sums the weights of ITS in-edges (degpart), the ranks all-reduce, and
+// the normalisation continues from the global degree (the added self loop counts once: + 1).
+__global__ void __launch_bounds__(kT) deg_partial(const float* __restrict__ w, int64_t N, const int* __restrict__ in_ptr,
+                                                 const int* __restrict__ in_src, const int* __restrict__ in_eid,
+                                                 float* __restrict__ degpart) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
+    if (i >= N) return;
+    float acc = 0.f;
+    for (int k = in_ptr[i] + lane; k < in_ptr[i + 1]; k += 64)
+        if (in_src[k] != static_cast<int>(i)) acc += w ? w[in_eid[k]] : 1.0f;
+    acc = wave_sum_all(acc);
+    if (lane == 0) degpart[i] = acc;
+}
+__global__ void __launch_bounds__(kT) dis_from_degree(const float* __restrict__ degsum, int64_t N, float* __restrict__ dis,
+                                                     float* __restrict__ loopw) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (i >= N) return;
+    float di = 1.0f / sqrtf(1.0f + degsum[i]);
+    if (isinf(di)) di = 0.f;
+    dis[i] = di;
+    loopw[i] = 1.0f;
+}
+// Y = act(X + bias) with the same fused ReLU / counter-based dropout as the SpMM epilogue.
+__global__ void __launch_bounds__(kT) bias_act(const float* __restrict__ X, const float* __restrict__ bias, int64_t N, int64_t D, int act,
+                                              float drop_scale, uint32_t drop_thresh, uint64_t seed, uint32_t site,
+                                              float* __restrict__ Y) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (idx >= N * D) return;
+    const int64_t i = idx / D;
+    const uint32_t c = static_cast<uint32_t>(idx - i * D);
+    float y = X[idx];
+    if (bias) y += bias[c];
+    if (act != SGS_ACT_NONE) y = fmaxf(y, 0.f);
+    if (act == SGS_ACT_RELU_DROPOUT) y = dropout_keep_at(seed, site, static_cast<uint64_t>(i), c, drop_thresh) ? y * drop_scale : 0.f;
+    Y[idx] = y;
+}
+
 // Normalised weights in both CSR orders (0 for loop entries, which the loop term replaces).
 __global__ void __launch_bounds__(kT) norm_weights(const float* __restrict__ w, int64_t N, int64_t n_edges,
                                                   const int* __restrict__ in_ptr, const int* __restrict__ in_src,
@@ -661,6 +699,46 @@ int sgs_gcn_norm_fwd(const float* w, int64_t n_edges, int64_t N, const int32_t* 
     hipLaunchKernelGGL(norm_deg, dim3(cdiv(N * 64, kT)), dim3(kT), 0, stream, w, N, in_ptr, in_src, in_eid, loop_eid, dis, loopw);
     hipLaunchKernelGGL(norm_weights, dim3(cdiv(2 * N * 64, kT)), dim3(kT), 0, stream, w, N, n_edges, in_ptr, in_src, in_eid,
                        out_ptr, out_dst, out_eid, dis, loopw, what_in, what_out, what_loop);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_gcn_degree_partial(const float* w, int64_t n_edges, int64_t N, const int32_t* in_ptr, const int32_t* in_src,
+                           const int32_t* in_eid, float* degpart, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && n_edges >= 0, SGS_EINVAL, "sgs_gcn_degree_partial: bad sizes");
+    if (N == 0) return SGS_OK;
+    SGS_REQUIRE(in_ptr && degpart, SGS_EINVAL, "sgs_gcn_degree_partial: null pointer");
+    hipLaunchKernelGGL(deg_partial, dim3(cdiv(N * 64, kT)), dim3(kT), 0, stream, w, N, in_ptr, in_src, in_eid, degpart);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_gcn_norm_from_degree(const float* w, const float* degsum, int64_t n_edges, int64_t N, const int32_t* in_ptr,
+                             const int32_t* in_src, const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_dst,
+                             const int32_t* out_eid, float* dis, float* loopw, float* what_in, float* what_out,
+                             float* what_loop, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && n_edges >= 0, SGS_EINVAL, "sgs_gcn_norm_from_degree: bad sizes");
+    if (N == 0) return SGS_OK;
+    SGS_REQUIRE(degsum && in_ptr && out_ptr && dis && loopw && what_loop, SGS_EINVAL, "sgs_gcn_norm_from_degree: null pointer");
+    hipLaunchKernelGGL(dis_from_degree, dim3(cdiv(N, kT)), dim3(kT), 0, stream, degsum, N, dis, loopw);
+    hipLaunchKernelGGL(norm_weights, dim3(cdiv(2 * N * 64, kT)), dim3(kT), 0, stream, w, N, n_edges, in_ptr, in_src, in_eid,
+                       out_ptr, out_dst, out_eid, dis, loopw, what_in, what_out, what_loop);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_bias_act(const float* X, const float* bias, int64_t N, int64_t D, int act, float p_drop, uint64_t seed, uint32_t site,
+                 float* Y, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && D >= 0 && D < (int64_t(1) << 32) && act >= SGS_ACT_NONE && act <= SGS_ACT_RELU_DROPOUT && p_drop >= 0.f &&
+                    p_drop < 1.f, SGS_EINVAL, "sgs_bias_act: bad arguments");
+    if (N * D == 0) return SGS_OK;
+    SGS_REQUIRE(X && Y, SGS_EINVAL, "sgs_bias_act: null pointer");
+    if (act == SGS_ACT_RELU_DROPOUT && p_drop == 0.f) act = SGS_ACT_RELU;
+    hipLaunchKernelGGL(bias_act, dim3(cdiv(N * D, kT)), dim3(kT), 0, stream, X, bias, N, D, act, 1.0f / (1.0f - p_drop),
+                       dropout_thresh(p_drop), seed, site, Y);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

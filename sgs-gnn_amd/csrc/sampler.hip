@@ -97,7 +97,7 @@ __device__ __forceinline__ float sample_prob(float pv, float Zeps, float mx, flo
 template <int MODE>
 __global__ void __launch_bounds__(kThreads) keys_hist0(const float* __restrict__ p, const float* __restrict__ prior,
                                                       const float* __restrict__ noise, uint64_t seed,
-                                                      uint64_t stream_id, int64_t E, float one_minus_c, float c,
+                                                      uint64_t stream_id, int64_t edge_offset, int64_t E, float one_minus_c, float c,
                                                       const float* __restrict__ scal, uint32_t* __restrict__ keys,
                                                       float* __restrict__ keys_out, uint32_t* __restrict__ hist) {
     __shared__ uint32_t lh[kBins];
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(kThreads) keys_hist0(const float* __restrict__
         const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
         if (e < E) {
             const float s = sample_prob<MODE>(p[e], Zeps, mx, has_prior ? prior[e] : 0.f, has_prior, one_minus_c, c);
-            const float nz = noise ? noise[e] : exp_noise_at(seed, stream_id, static_cast<uint64_t>(e));
+            const float nz = noise ? noise[e] : exp_noise_at(seed, stream_id, static_cast<uint64_t>(edge_offset + e));
             const float key = __fdiv_rn(s, nz);
             const uint32_t bits = __float_as_uint(key);
             keys[e] = bits;
@@ -263,14 +263,14 @@ __global__ void __launch_bounds__(kThreads) scan_blocks(uint2* __restrict__ cnt,
     }
 }
 
-__global__ void __launch_bounds__(kThreads) compact(const uint32_t* __restrict__ keys, int64_t E, int64_t q,
-                                                   const SelectState* __restrict__ st, const uint2* __restrict__ cnt,
+__global__ void __launch_bounds__(kThreads) compact(const uint32_t* __restrict__ keys, int64_t E, int64_t q, int64_t ties_override,
+                                                   int64_t eid_offset, const SelectState* __restrict__ st, const uint2* __restrict__ cnt,
                                                    const float* __restrict__ p, const int64_t* __restrict__ edge_index,
                                                    uint8_t* __restrict__ mask, int mask_aligned,
                                                    int64_t* __restrict__ sampled_eid, int64_t* __restrict__ sei,
                                                    float* __restrict__ sampled_p) {
     __shared__ uint32_t wg[kThreads / 64], we[kThreads / 64];
-    const uint32_t T = st->prefix, k_rem = st->k_rem;
+    const uint32_t T = st->prefix, k_rem = ties_override >= 0 ? static_cast<uint32_t>(ties_override) : st->k_rem;
     const int64_t e0 = static_cast<int64_t>(blockIdx.x) * kChunk + static_cast<int64_t>(threadIdx.x) * kItems;
     uint32_t k[kItems];
     load_keys8(keys, e0, E, k);
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(kThreads) compact(const uint32_t* __restrict__
             if (sel) {
                 mbits |= (uint64_t(1) << (8 * j));
                 const int64_t pos = static_cast<int64_t>(bg) + static_cast<int64_t>(be < k_rem ? be : k_rem);
-                if (sampled_eid) sampled_eid[pos] = e;
+                if (sampled_eid) sampled_eid[pos] = eid_offset + e;
                 if (sei) {
                     sei[pos] = edge_index[e];
                     sei[q + pos] = edge_index[E + e];
@@ -322,6 +322,23 @@ __global__ void __launch_bounds__(kThreads) compact(const uint32_t* __restrict__
 #pragma unroll
         for (int j = 0; j < kItems; ++j)
             if (e0 + j < E) mask[e0 + j] = static_cast<uint8_t>((mbits >> (8 * j)) & 1u);
+    }
+}
+
+// counts[0] = #keys > threshold, counts[1] = #keys == threshold in this shard (before the scan).
+__global__ void __launch_bounds__(kThreads) total_counts(const uint2* __restrict__ cnt, int64_t nblk, uint32_t* __restrict__ counts) {
+    __shared__ int red[2 * (kThreads / 64)];
+    int g = 0, e = 0;
+    for (int64_t i = threadIdx.x; i < nblk; i += kThreads) { g += static_cast<int>(cnt[i].x); e += static_cast<int>(cnt[i].y); }
+    g = wave_sum_int_all(g);
+    e = wave_sum_int_all(e);
+    if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = g; red[2 * (threadIdx.x >> 6) + 1] = e; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int G = 0, Q = 0;
+        for (int w = 0; w < kThreads / 64; ++w) { G += red[2 * w]; Q += red[2 * w + 1]; }
+        counts[0] = static_cast<uint32_t>(G);
+        counts[1] = static_cast<uint32_t>(Q);
     }
 }
 
@@ -531,10 +548,10 @@ int sgs_sample_topq(int mode, const float* p, const float* prior, double degree_
     const float one_minus_c = static_cast<float>(1.0 - degree_bias_coef);
     const float c = static_cast<float>(degree_bias_coef);
     if (mode == SGS_SAMPLE_LEARNED)
-        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_LEARNED>, grid, blk, 0, stream, p, prior, noise, seed, stream_id, E,
+        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_LEARNED>, grid, blk, 0, stream, p, prior, noise, seed, stream_id, int64_t(0), E,
                            one_minus_c, c, scal, keys, keys_out, hist);
     else
-        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_PRIOR>, grid, blk, 0, stream, p, nullptr, noise, seed, stream_id, E,
+        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_PRIOR>, grid, blk, 0, stream, p, nullptr, noise, seed, stream_id, int64_t(0), E,
                            one_minus_c, c, scal, keys, keys_out, hist);
     hipLaunchKernelGGL(select_digit, dim3(1), blk, 0, stream, hist, kShift0, 1, static_cast<uint32_t>(q), st);
     hipLaunchKernelGGL(hist_next, grid, blk, 0, stream, keys, E, kShift1, kMask1, kShift0, st, hist);
@@ -544,9 +561,122 @@ int sgs_sample_topq(int mode, const float* p, const float* prior, double degree_
     hipLaunchKernelGGL(count_blocks, grid, blk, 0, stream, keys, E, st, cnt);
     hipLaunchKernelGGL(scan_blocks, dim3(1), blk, 0, stream, cnt, nblk);
     const int mask_aligned = (reinterpret_cast<uintptr_t>(mask) & 7) == 0;
-    hipLaunchKernelGGL(compact, grid, blk, 0, stream, keys, E, q, st, cnt, p, edge_index, mask, mask_aligned,
+    hipLaunchKernelGGL(compact, grid, blk, 0, stream, keys, E, q, int64_t(-1), int64_t(0), st, cnt, p, edge_index, mask, mask_aligned,
                        sampled_eid, sampled_edge_index, sampled_p);
     if (stats) hipLaunchKernelGGL(write_stats, dim3(1), dim3(1), 0, stream, scal, st, stats);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+
+/* ---------------------------------------------------------------- phase API (edge-sharded draws)
+ * The same kernels as sgs_sample_topq, exposed per phase so that R ranks holding contiguous,
+ * 2048-aligned shards of the edge list can run ONE exact global draw: per-chunk partial sums are
+ * all-gathered and reduced in the single-GPU order (bit-identical Z), digit histograms are
+ * all-reduced (integers), every rank runs the same digit selection, ties at the threshold go to the
+ * lowest GLOBAL edge ids, and compaction is local.  Noise is keyed by the global edge id. */
+size_t sgs_sampler_shard_workspace_bytes(int64_t E_local) {
+    if (E_local < 0) E_local = 0;
+    return carve_bytes(E_local, 4) + carve_bytes(cdiv(E_local, kChunk) + 1, sizeof(uint2)) + 256;
+}
+int64_t sgs_sampler_chunk(void) { return kChunk; }
+
+int sgs_sampler_shard_partials(int stage, const float* p, int64_t E, const float* scal, float* part, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(stage >= 0 && stage <= 2 && E >= 0, SGS_EINVAL, "sgs_sampler_shard_partials: bad arguments");
+    if (E == 0) return SGS_OK;
+    SGS_REQUIRE(p && part && (stage != 2 || scal), SGS_EINVAL, "sgs_sampler_shard_partials: null pointer");
+    const dim3 grid(static_cast<unsigned>(cdiv(E, kChunk))), blk(kThreads);
+    if (stage == 0) hipLaunchKernelGGL(reduce_partial<0>, grid, blk, 0, stream, p, E, scal, part);
+    else if (stage == 1) hipLaunchKernelGGL(reduce_partial<1>, grid, blk, 0, stream, p, E, scal, part);
+    else hipLaunchKernelGGL(reduce_partial<2>, grid, blk, 0, stream, p, E, scal, part);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_sampler_shard_finalize(int stage, const float* part_all, int64_t nblk_all, float* scal, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(stage >= 0 && stage <= 2 && nblk_all >= 0 && scal && (nblk_all == 0 || part_all), SGS_EINVAL,
+                "sgs_sampler_shard_finalize: bad arguments");
+    if (stage == 1) hipLaunchKernelGGL(reduce_final<1>, dim3(1), dim3(kThreads), 0, stream, part_all, nblk_all, scal);
+    else hipLaunchKernelGGL(reduce_final<0>, dim3(1), dim3(kThreads), 0, stream, part_all, nblk_all, scal);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_sampler_shard_keys(int mode, const float* p, const float* prior, double degree_bias_coef, const float* noise,
+                           uint64_t seed, uint64_t stream_id, int64_t edge_offset, int64_t E, const float* scal, uint32_t* keys,
+                           float* keys_out, uint32_t* hist, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE((mode == SGS_SAMPLE_LEARNED || mode == SGS_SAMPLE_PRIOR) && E >= 0 && edge_offset >= 0, SGS_EINVAL,
+                "sgs_sampler_shard_keys: bad arguments");
+    if (E == 0) return SGS_OK;
+    SGS_REQUIRE(p && scal && keys && hist, SGS_EINVAL, "sgs_sampler_shard_keys: null pointer");
+    const float one_minus_c = static_cast<float>(1.0 - degree_bias_coef), c = static_cast<float>(degree_bias_coef);
+    const dim3 grid(static_cast<unsigned>(cdiv(E, kChunk))), blk(kThreads);
+    if (mode == SGS_SAMPLE_LEARNED)
+        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_LEARNED>, grid, blk, 0, stream, p, prior, noise, seed, stream_id, edge_offset, E,
+                           one_minus_c, c, scal, keys, keys_out, hist);
+    else
+        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_PRIOR>, grid, blk, 0, stream, p, nullptr, noise, seed, stream_id, edge_offset, E,
+                           one_minus_c, c, scal, keys, keys_out, hist);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_sampler_shard_hist(const uint32_t* keys, int64_t E, int pass, const void* state, uint32_t* hist, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE((pass == 1 || pass == 2) && E >= 0 && state && hist, SGS_EINVAL, "sgs_sampler_shard_hist: bad arguments");
+    if (E == 0) return SGS_OK;
+    const dim3 grid(static_cast<unsigned>(cdiv(E, kChunk))), blk(kThreads);
+    if (pass == 1) hipLaunchKernelGGL(hist_next, grid, blk, 0, stream, keys, E, kShift1, kMask1, kShift0, static_cast<const SelectState*>(state), hist);
+    else hipLaunchKernelGGL(hist_next, grid, blk, 0, stream, keys, E, kShift2, kMask2, kShift1, static_cast<const SelectState*>(state), hist);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_sampler_select(uint32_t* hist, int pass, int64_t q, void* state, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(pass >= 0 && pass <= 2 && q > 0 && hist && state, SGS_EINVAL, "sgs_sampler_select: bad arguments");
+    const int shift = pass == 0 ? kShift0 : pass == 1 ? kShift1 : kShift2;
+    hipLaunchKernelGGL(select_digit, dim3(1), dim3(kThreads), 0, stream, hist, shift, pass == 0 ? 1 : 0, static_cast<uint32_t>(q),
+                       static_cast<SelectState*>(state));
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_sampler_shard_count(const uint32_t* keys, int64_t E, const void* state, uint32_t* counts, void* ws, size_t ws_bytes,
+                            sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(E >= 0 && state && counts, SGS_EINVAL, "sgs_sampler_shard_count: bad arguments");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_sampler_shard_workspace_bytes(E), SGS_EWORKSPACE, "sgs_sampler_shard_count: workspace too small");
+    Carver cv(ws);
+    cv.take<uint32_t>(E);                                  // keys live in the caller's copy of this region
+    uint2* cnt = cv.take<uint2>(cdiv(E, kChunk) + 1);
+    const int64_t nblk = cdiv(E, kChunk);
+    if (nblk > 0) hipLaunchKernelGGL(count_blocks, dim3(nblk), dim3(kThreads), 0, stream, keys, E, static_cast<const SelectState*>(state), cnt);
+    hipLaunchKernelGGL(total_counts, dim3(1), dim3(kThreads), 0, stream, cnt, nblk, counts);
+    if (nblk > 0) hipLaunchKernelGGL(scan_blocks, dim3(1), dim3(kThreads), 0, stream, cnt, nblk);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_sampler_shard_compact(const uint32_t* keys, int64_t E, const void* state, int64_t ties_local, int64_t q_local,
+                              int64_t edge_offset, const float* p, const int64_t* edge_index_local, uint8_t* mask,
+                              int64_t* sampled_eid, int64_t* sampled_edge_index, float* sampled_p, void* ws, size_t ws_bytes,
+                              sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(E >= 0 && ties_local >= 0 && q_local >= 0 && state, SGS_EINVAL, "sgs_sampler_shard_compact: bad arguments");
+    if (E == 0) return SGS_OK;
+    SGS_REQUIRE(keys && mask && p, SGS_EINVAL, "sgs_sampler_shard_compact: null pointer");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_sampler_shard_workspace_bytes(E), SGS_EWORKSPACE, "sgs_sampler_shard_compact: workspace too small");
+    Carver cv(ws);
+    cv.take<uint32_t>(E);
+    uint2* cnt = cv.take<uint2>(cdiv(E, kChunk) + 1);      // scanned by sgs_sampler_shard_count
+    const int mask_aligned = (reinterpret_cast<uintptr_t>(mask) & 7) == 0;
+    hipLaunchKernelGGL(compact, dim3(cdiv(E, kChunk)), dim3(kThreads), 0, stream, keys, E, q_local, ties_local, edge_offset,
+                       static_cast<const SelectState*>(state), cnt, p, edge_index_local, mask, mask_aligned, sampled_eid,
+                       sampled_edge_index, sampled_p);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

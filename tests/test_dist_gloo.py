@@ -59,3 +59,17 @@ def test_gradsync_world2_gloo():
         p.join(60)
         assert p.exitcode == 0
     assert res == [(0, True, False), (1, True, False)]
+
+
+def test_shard_bounds_are_chunk_aligned_and_cover_everything():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import sgs_gnn_amd  # noqa: F401
+    from importlib import import_module
+    sh = import_module("sgs_gnn_amd.sharded")
+    for E in (1, 2047, 2048, 2049, 50000, 114_615_892):
+        for world in (1, 2, 3, 8):
+            b = sh.shard_bounds(E, world, 2048)
+            assert b[0] == 0 and b[-1] == E and len(b) == world + 1
+            assert all(b[i] <= b[i + 1] for i in range(world))
+            assert all(x % 2048 == 0 for x in b[:-1])             # every interior boundary on a reduction-chunk boundary
