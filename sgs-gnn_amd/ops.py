@@ -31,7 +31,16 @@ def _ptr(t, dtype=None):
     return t.data_ptr()
 
 
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream            # fast path: no Stream object per call
+except AttributeError:                                         # pragma: no cover
+    _raw_stream = None
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device, as an integer."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -141,14 +150,15 @@ class Graph:
         dev = ei.device
         n = ei.shape[1]
         self.edge_index, self.n_edges, self.N = ei, n, int(N)
-        i32 = dict(dtype=torch.int32, device=dev)
-        self.in_ptr = torch.empty(N + 1, **i32)
-        self.out_ptr = torch.empty(N + 1, **i32)
-        self.in_src = torch.empty(max(n, 1), **i32)
-        self.in_eid = torch.empty(max(n, 1), **i32)
-        self.out_dst = torch.empty(max(n, 1), **i32)
-        self.out_eid = torch.empty(max(n, 1), **i32)
-        self.loop_eid = torch.empty(max(N, 1), **i32)
+        # one allocation, seven views (host time matters: the step is launch-bound at partition scale)
+        ne = max(n, 1)
+        sizes = [N + 1, N + 1, ne, ne, ne, ne, max(N, 1)]
+        offs = [0]
+        for z in sizes:
+            offs.append(offs[-1] + ((z + 63) & ~63))             # keep every view 256-B aligned
+        buf = torch.empty(offs[-1], dtype=torch.int32, device=dev)
+        (self.in_ptr, self.out_ptr, self.in_src, self.in_eid, self.out_dst, self.out_eid, self.loop_eid) = (
+            buf[offs[i]:offs[i] + sizes[i]] for i in range(7))
         nws = L.sgs_graph_build_workspace_bytes(n, N)
         ws = workspace(nws, dev)
         _lib.check(L.sgs_graph_build(_ptr(ei), n, N, _ptr(self.in_ptr), _ptr(self.in_src), _ptr(self.in_eid),
@@ -182,12 +192,13 @@ def _norm_forward(graph: Graph, w):
     dev = graph.edge_index.device
     nm = Norm()
     nm.graph, nm.w = graph, w
-    f32 = dict(dtype=torch.float32, device=dev)
-    nm.dis = torch.empty(graph.N, **f32)
-    nm.loopw = torch.empty(graph.N, **f32)
-    nm.what_in = torch.empty(max(graph.n_edges, 1), **f32)
-    nm.what_out = torch.empty(max(graph.n_edges, 1), **f32)
-    nm.what_loop = torch.empty(graph.N, **f32)
+    ne, Nn = max(graph.n_edges, 1), graph.N
+    sizes = [Nn, Nn, ne, ne, Nn]
+    offs = [0]
+    for z in sizes:
+        offs.append(offs[-1] + ((z + 63) & ~63))
+    buf = torch.empty(offs[-1], dtype=torch.float32, device=dev)
+    nm.dis, nm.loopw, nm.what_in, nm.what_out, nm.what_loop = (buf[offs[i]:offs[i] + sizes[i]] for i in range(5))
     nm.handle = None
     _lib.check(L.sgs_gcn_norm_fwd(_ptr(w, torch.float32), graph.n_edges, graph.N, _ptr(graph.in_ptr), _ptr(graph.in_src),
                                   _ptr(graph.in_eid), _ptr(graph.out_ptr), _ptr(graph.out_dst), _ptr(graph.out_eid),
@@ -395,11 +406,12 @@ def _u8(mask: torch.Tensor) -> torch.Tensor:
     raise RuntimeError("mask must be a bool tensor")
 
 
-def masked_correct(logits, y, train_mask) -> torch.Tensor:
+def masked_correct(logits, y, train_mask, out=None) -> torch.Tensor:
     """int32 [2] on device: (#correct argmax on train rows, #train rows) -- no host sync."""
     L = _lib.lib()
     _need_gpu(logits, y, train_mask)
-    out = torch.empty(2, dtype=torch.int32, device=logits.device)
+    if out is None:
+        out = torch.empty(2, dtype=torch.int32, device=logits.device)
     N, C = logits.shape
     _lib.check(L.sgs_masked_correct(_ptr(logits.contiguous(), torch.float32), N, C, _ptr(y, torch.int64), _ptr(_u8(train_mask)),
                                     _ptr(out), _stream()), "sgs_masked_correct")

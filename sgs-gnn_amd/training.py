@@ -144,8 +144,11 @@ def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edg
                 counts = None
                 if args.conditional:
                     random_out = model(batch, rsei)
-                    counts = torch.stack([ops.masked_correct(learned_out, batch.y, batch.train_mask),
-                                          ops.masked_correct(random_out, batch.y, batch.train_mask)]).tolist()
+                    cbuf = torch.empty(4, dtype=torch.int32, device=learned_out.device)
+                    ops.masked_correct(learned_out, batch.y, batch.train_mask, out=cbuf[0:2])
+                    ops.masked_correct(random_out, batch.y, batch.train_mask, out=cbuf[2:4])
+                    counts = cbuf.tolist()                                         # the step's one host read-back
+                    counts = [counts[0:2], counts[2:4]]
                     # learned_f1 > random_f1 with f1 = correct / n_train on both sides (utils.py:163-169)
                     update_edge_mlp = counts[0][0] > counts[1][0]
 
