@@ -174,6 +174,16 @@ int sgs_gcn_norm_from_degree(const float* w, const float* degsum, int64_t n_edge
 int sgs_bias_act(const float* X, const float* bias, int64_t N, int64_t D, int act, float p_drop, uint64_t seed,
                  uint32_t site, float* Y, sgs_stream_t stream);
 
+/* GraphSAGE mean aggregation for the GSAGE scorer (model.py:47-89, PyG SAGEConv aggr='mean'): per-entry
+ * weights 1 / indeg(dst) in both CSR orders, to be used with sgs_spmm_csr (diag = NULL).
+ * sgs_degree_prior_logits: the argument of the softmax in datasets.py:141-156 (`add_degree`),
+ * E^-1/2 / (colcount[row_e] + rowcount[col_e] + 1e-10); the softmax itself is the sampler's prior mode,
+ * or torch.softmax when the materialised `data.prob` is wanted. */
+int sgs_mean_weights(int64_t n_edges, int64_t N, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_dst,
+                     float* what_in, float* what_out, sgs_stream_t stream);
+int sgs_degree_prior_logits(const int64_t* edge_index, int64_t E, int64_t N, const int32_t* in_ptr,
+                            const int32_t* out_ptr, float* logits, sgs_stream_t stream);
+
 /* gcn_norm backward: from gw_hat[e] = dL/d(what_e) (edge-id order) and gloop[i] = dL/d(what_loop_i)
  * to dL/dw_e, through both the message weight and the degree normalisation:
  *   dw_e = gw_hat_e dis_s dis_t + Hn_t,            Hn_t = -1/2 dis_t^3 G_t

@@ -204,6 +204,27 @@ def gat_conv(x, edge_index, lin_w, att_src, att_dst, bias, negative_slope=0.2, a
 
 
 # --------------------------------------------------------------------------------------
+# SAGE layer (PyG 2.3.1 SAGEConv defaults; PARITY UNPINNED) and EdgeProbSAGE (model.py:47-89)
+# --------------------------------------------------------------------------------------
+def sage_conv(x, edge_index, lin_l_w, lin_l_b, lin_r_w):
+    """out_i = lin_l(mean_{j->i} x_j) + lin_r(x_i): mean over in-edges (duplicates and (i,i) counted, none added)."""
+    N = x.shape[0]
+    cnt = torch.zeros(N, dtype=x.dtype).index_add(0, edge_index[1], torch.ones(edge_index.shape[1], dtype=x.dtype))
+    agg = torch.zeros(N, x.shape[1], dtype=x.dtype).index_add(0, edge_index[1], x[edge_index[0]])
+    agg = agg / cnt.clamp(min=1).unsqueeze(1)
+    return agg @ lin_l_w.t() + lin_l_b + x @ lin_r_w.t()
+
+
+def edge_prob_sage(P, x, edge_index, rsei=None, p=0.0, masks=None):
+    g = rsei if rsei is not None else edge_index
+    out = F.relu(sage_conv(x, g, P["edge_prob_mlp.gcn1.lin_l.weight"], P["edge_prob_mlp.gcn1.lin_l.bias"],
+                           P["edge_prob_mlp.gcn1.lin_r.weight"]))
+    out = _drop(out, None if masks is None else masks.enc_hidden, p)
+    return edge_score(out[edge_index[0]], out[edge_index[1]], P["edge_prob_mlp.fc1.weight"], P["edge_prob_mlp.fc1.bias"],
+                      P["edge_prob_mlp.fc2.weight"], P["edge_prob_mlp.fc2.bias"], p, None if masks is None else masks.score_hidden)
+
+
+# --------------------------------------------------------------------------------------
 # dropout with explicit keep-masks
 # --------------------------------------------------------------------------------------
 def _drop(x, keep, p):

@@ -4,7 +4,7 @@ include/sgs_hip.h); this package is the host-side mirror of the reference's call
 (model.py, sampling.py, training*.py, utils.py).  No CPU fallback exists."""
 from . import _lib, ops  # noqa: F401
 from .model import GCNConv, GNNModel, GATConv, GAT, GATModel, set_dropout_seed  # noqa: F401
-from .scorer import EdgeProbGCN, EdgeProbMLP, EdgeProbSAGE, get_edge_mlp  # noqa: F401
+from .scorer import EdgeProbGCN, EdgeProbMLP, EdgeProbSAGE, SAGEConv, get_edge_mlp  # noqa: F401
 from .sampling import gumbel_softmax_sampling, random_edge_sampling, manual_seed  # noqa: F401
 from .training import train, train_hybrid, train_straight_through, train_two_pass  # noqa: F401
 from .evaluate import evaluate, ensemble_evaluate  # noqa: F401

@@ -274,6 +274,40 @@ __global__ void __launch_bounds__(kT) bias_act(const float* __restrict__ X, cons
     Y[idx] = y;
 }
 
+// GraphSAGE mean aggregation (PyG SAGEConv aggr='mean': mean over in-edges, duplicates and (i,i) edges
+// counted, no loops added): entry weight 1 / indeg(dst) in both CSR orders.
+__global__ void __launch_bounds__(kT) mean_weights(int64_t N, const int* __restrict__ in_ptr, const int* __restrict__ out_ptr,
+                                                  const int* __restrict__ out_dst, float* __restrict__ what_in,
+                                                  float* __restrict__ what_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
+    if (r >= 2 * N) return;
+    if (r < N) {
+        const int b = in_ptr[r], e = in_ptr[r + 1];
+        const float w = e > b ? 1.0f / static_cast<float>(e - b) : 0.f;
+        for (int k = b + lane; k < e; k += 64) what_in[k] = w;
+    } else {
+        const int64_t i = r - N;
+        for (int k = out_ptr[i] + lane; k < out_ptr[i + 1]; k += 64) {
+            const int t = out_dst[k];
+            what_out[k] = 1.0f / static_cast<float>(in_ptr[t + 1] - in_ptr[t]);
+        }
+    }
+}
+
+// datasets.py:141-156 `add_degree` (before its softmax): logit_e = E^-1/2 / (colcount[row_e] + rowcount[col_e] + 1e-10),
+// colcount = in-degree, rowcount = out-degree, read off the two CSR pointer arrays.
+__global__ void __launch_bounds__(kT) degree_prior_logits(const int64_t* __restrict__ ei, int64_t E, const int* __restrict__ in_ptr,
+                                                         const int* __restrict__ out_ptr, float scale, float* __restrict__ logit) {
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (e >= E) return;
+    const int r = static_cast<int>(ei[e]), c = static_cast<int>(ei[E + e]);
+    const float colcount_r = static_cast<float>(in_ptr[r + 1] - in_ptr[r]);
+    const float rowcount_c = static_cast<float>(out_ptr[c + 1] - out_ptr[c]);
+    const float prob = 1.0f / ((colcount_r + rowcount_c) + 1e-10f);
+    logit[e] = prob * scale;
+}
+
 // Normalised weights in both CSR orders (0 for loop entries, which the loop term replaces).
 __global__ void __launch_bounds__(kT) norm_weights(const float* __restrict__ w, int64_t N, int64_t n_edges,
                                                   const int* __restrict__ in_ptr, const int* __restrict__ in_src,
@@ -739,6 +773,29 @@ int sgs_bias_act(const float* X, const float* bias, int64_t N, int64_t D, int ac
     if (act == SGS_ACT_RELU_DROPOUT && p_drop == 0.f) act = SGS_ACT_RELU;
     hipLaunchKernelGGL(bias_act, dim3(cdiv(N * D, kT)), dim3(kT), 0, stream, X, bias, N, D, act, 1.0f / (1.0f - p_drop),
                        dropout_thresh(p_drop), seed, site, Y);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_mean_weights(int64_t n_edges, int64_t N, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_dst,
+                     float* what_in, float* what_out, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && n_edges >= 0, SGS_EINVAL, "sgs_mean_weights: bad sizes");
+    if (N == 0 || n_edges == 0) return SGS_OK;
+    SGS_REQUIRE(in_ptr && out_ptr && out_dst && what_in && what_out, SGS_EINVAL, "sgs_mean_weights: null pointer");
+    hipLaunchKernelGGL(mean_weights, dim3(cdiv(2 * N * 64, kT)), dim3(kT), 0, stream, N, in_ptr, out_ptr, out_dst, what_in, what_out);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_degree_prior_logits(const int64_t* edge_index, int64_t E, int64_t N, const int32_t* in_ptr, const int32_t* out_ptr,
+                            float* logits, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && E >= 0, SGS_EINVAL, "sgs_degree_prior_logits: bad sizes");
+    if (E == 0) return SGS_OK;
+    SGS_REQUIRE(edge_index && in_ptr && out_ptr && logits, SGS_EINVAL, "sgs_degree_prior_logits: null pointer");
+    const float scale = static_cast<float>(1.0 / sqrt(static_cast<double>(E)));          // len(prob) ** -0.5
+    hipLaunchKernelGGL(degree_prior_logits, dim3(cdiv(E, kT)), dim3(kT), 0, stream, edge_index, E, in_ptr, out_ptr, scale, logits);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

@@ -300,7 +300,7 @@ def gcn_propagate(X, nm: Norm, bias=None, act=ACT_NONE, p=0.0, seed=0, site=0):
     """K5: act(A_hat X + bias) with autograd to X, bias and (through nm.handle) the edge weights."""
     _need_gpu(X, bias)
     if X.dtype != torch.float32 or X.dim() != 2 or X.shape[0] != nm.graph.N:
-        raise RuntimeError("gcn_propagate: X must be float32 [N, D]")
+        raise RuntimeError("gcn_propagate: X must be float32 [N, D]")    # nm.what_loop may be None (no self-loop term)
     return _Propagate.apply(X.contiguous(), nm.handle, bias, nm, act, float(p), int(seed), int(site))
 
 
@@ -589,3 +589,30 @@ class _LinearNoBias(torch.autograd.Function):
 def linear_nobias(x, W):
     _need_gpu(x, W)
     return _LinearNoBias.apply(x, W)
+
+
+# ------------------------------------------------------------------ GraphSAGE mean aggregation, device-side degree prior
+def mean_norm(graph: Graph) -> Norm:
+    """Norm-like object for SAGEConv's mean aggregation: weights 1/indeg(dst), no self-loop term."""
+    L = _lib.lib()
+    dev = graph.edge_index.device
+    nm = Norm()
+    nm.graph, nm.w, nm.handle, nm.dis, nm.loopw, nm.what_loop = graph, None, None, None, None, None
+    ne = max(graph.n_edges, 1)
+    nm.what_in = torch.empty(ne, dtype=torch.float32, device=dev)
+    nm.what_out = torch.empty(ne, dtype=torch.float32, device=dev)
+    _lib.check(L.sgs_mean_weights(graph.n_edges, graph.N, _ptr(graph.in_ptr), _ptr(graph.out_ptr), _ptr(graph.out_dst),
+                                  _ptr(nm.what_in), _ptr(nm.what_out), _stream()), "sgs_mean_weights")
+    return nm
+
+
+def degree_prior(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """`data.prob` of datasets.py:141-156 (add_degree) computed on the device."""
+    L = _lib.lib()
+    _need_gpu(edge_index)
+    g = get_graph(edge_index, num_nodes)
+    E = edge_index.shape[1]
+    logits = torch.empty(E, dtype=torch.float32, device=edge_index.device)
+    _lib.check(L.sgs_degree_prior_logits(_ptr(g.edge_index), E, num_nodes, _ptr(g.in_ptr), _ptr(g.out_ptr), _ptr(logits), _stream()),
+               "sgs_degree_prior_logits")
+    return torch.softmax(logits, dim=0)

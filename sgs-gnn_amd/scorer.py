@@ -73,12 +73,49 @@ class EdgeProbMLP(nn.Module):
         return prob.unsqueeze(1)
 
 
-class EdgeProbSAGE(nn.Module):
-    """model.py:47-89 (`--edge_mlp_type GSAGE`): outside the round-1 scope (SURVEY.md section 8f #3)."""
+class SAGEConv(nn.Module):
+    """PyG 2.3.1 SAGEConv(in, out) with its defaults (aggr='mean', root_weight=True, bias=True):
+    out_i = lin_l(mean_{j -> i} x_j) + lin_r(x_i); keys `lin_l.weight`, `lin_l.bias`, `lin_r.weight`.
+    The mean commutes with lin_l, so the aggregation runs on the H-wide transformed features."""
 
-    def __init__(self, *a, **k):
+    def __init__(self, in_channels, out_channels):
         super().__init__()
-        raise NotImplementedError("EdgeProbSAGE (GSAGE scorer) is not part of the MI355X hot path yet")
+        self.lin_l = nn.Linear(in_channels, out_channels, bias=True)
+        self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
+
+    def forward(self, x, edge_index, *, act=ops.ACT_NONE, p=0.0, seed=0, site=0):
+        nm = ops.mean_norm(ops.get_graph(edge_index, x.shape[0]))
+        agg = ops.gcn_propagate(ops.linear_nobias(x, self.lin_l.weight), nm, None)
+        out = agg + self.lin_l.bias + ops.linear_nobias(x, self.lin_r.weight)
+        if act != ops.ACT_NONE:
+            out = F.relu(out)
+            if act == ops.ACT_RELU_DROPOUT and p > 0:
+                keep = ops.dropout_keep(seed, site, out.shape[0], out.shape[1], p, out.device)
+                out = out * keep / (1.0 - p)
+        return out
+
+
+class EdgeProbSAGE(nn.Module):
+    """model.py:47-89 (`--edge_mlp_type GSAGE`): one SAGEConv encoder over `random_sampled_edge_index`
+    (or `edge_index`), dropout(relu(.)), then `_edge_score` for every column of `edge_index`."""
+
+    def __init__(self, in_channels, hidden_dim, dropout_prob=0.2):
+        super().__init__()
+        self.gcn1 = SAGEConv(in_channels, hidden_dim)
+        self.fc1 = nn.Linear(2 * hidden_dim, hidden_dim)
+        self.dropout = nn.Dropout(dropout_prob)
+        self.fc2 = nn.Linear(hidden_dim, 1)
+        self.last_active = None
+
+    def forward(self, node_features, edge_index, random_sampled_edge_index=None, use_checkpoint=False):
+        g = random_sampled_edge_index if random_sampled_edge_index is not None else edge_index
+        p = self.dropout.p if self.training else 0.0
+        act = ops.ACT_RELU_DROPOUT if p > 0 else ops.ACT_RELU
+        out = self.gcn1(node_features, g, act=act, p=p, seed=_DropoutClock.next_seed(), site=SITE_ENC)
+        self.last_active = ops.ActiveSet()
+        prob = ops.edge_score(out, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, edge_index,
+                              active=self.last_active, p=p, seed=_DropoutClock.next_seed(), site=SITE_SCORE)
+        return prob.unsqueeze(1)
 
 
 def get_edge_mlp(in_channels, hidden_dim, dropout_prob, edge_mlp_type='MLP'):
