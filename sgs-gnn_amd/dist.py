@@ -27,41 +27,48 @@ def shard_batches(batches, rank: int, world: int):
 
 
 class GradSync:
-    """Flat-bucket gradient averaging over the default process group."""
+    """Flat-bucket gradient averaging over the default process group.
+
+    Per step: one `_foreach_copy_` packs the present gradients into views of ONE persistent fp32
+    bucket (absent gradients are zeroed views), one all-reduce sums it, one scale averages it, and the
+    parameters' `.grad` are pointed at the views (no unpack copies).  No host synchronisation."""
 
     def __init__(self, params):
         self.params = [p for p in params]
-        self.numel = sum(p.numel() for p in self.params)
+        self.sizes = [p.numel() for p in self.params]
+        self.numel = sum(self.sizes)
         self.flat = None
+        self.views = None
 
-    def sync(self, learned_flag: bool) -> bool:
-        """Average all .grad tensors across ranks (missing grads count as zeros).  Returns True iff
-        any rank's gate chose "learned" this step."""
+    def _ensure(self, device):
+        if self.flat is None or self.flat.device != device:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
+            self.views = [v.view_as(p) for v, p in zip(self.flat.split(self.sizes), self.params)]
+
+    def any_learned(self, learned_local: torch.Tensor) -> torch.Tensor:
+        """Device-side: sum over ranks of this rank's 0/1 gate outcome (enqueue BEFORE the gate read-back)."""
+        if is_parallel():
+            dist.all_reduce(learned_local, op=dist.ReduceOp.SUM)
+        return learned_local
+
+    def sync(self) -> None:
+        """Average all .grad tensors across ranks (missing grads count as zeros); afterwards every
+        parameter's .grad is a view of the shared bucket."""
         if not is_parallel():
-            return learned_flag
-        p0 = self.params[0]
-        if self.flat is None or self.flat.device != p0.device:
-            self.flat = torch.zeros(self.numel + 1, dtype=torch.float32, device=p0.device)
-        flat = self.flat
-        off = 0
-        for p in self.params:
-            n = p.numel()
+            return
+        self._ensure(self.params[0].device)
+        have_v, have_g, miss_v = [], [], []
+        for p, v in zip(self.params, self.views):
             if p.grad is None:
-                flat[off:off + n].zero_()
-            else:
-                flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
-        flat[off] = 1.0 if learned_flag else 0.0
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        world = dist.get_world_size()
-        any_learned = bool(flat[off].item() > 0.5)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            g = flat[off:off + n].view_as(p) / world
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            off += n
-        return any_learned
+                miss_v.append(v)
+            elif p.grad.data_ptr() != v.data_ptr():
+                have_v.append(v)
+                have_g.append(p.grad)
+        if have_v:
+            torch._foreach_copy_(have_v, have_g)
+        if miss_v:
+            torch._foreach_zero_(miss_v)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.flat.div_(dist.get_world_size())
+        for p, v in zip(self.params, self.views):
+            p.grad = v

@@ -142,16 +142,22 @@ def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edg
                 update_edge_mlp = True
                 random_out = None
                 counts = None
+                any_learned = False
                 if args.conditional:
                     random_out = model(batch, rsei)
-                    cbuf = torch.empty(4, dtype=torch.int32, device=learned_out.device)
+                    cbuf = torch.empty(5, dtype=torch.int32, device=learned_out.device)
                     ops.masked_correct(learned_out, batch.y, batch.train_mask, out=cbuf[0:2])
                     ops.masked_correct(random_out, batch.y, batch.train_mask, out=cbuf[2:4])
+                    if sync is not None:            # N > 1: does ANY rank's gate choose "learned"? (device-side, no extra sync)
+                        cbuf[4:5] = sync.any_learned((cbuf[0:1] > cbuf[2:3]).to(torch.int32))
                     counts = cbuf.tolist()                                         # the step's one host read-back
+                    any_learned = sync is not None and counts[4] > 0
                     counts = [counts[0:2], counts[2:4]]
                     # learned_f1 > random_f1 with f1 = correct / n_train on both sides (utils.py:163-169)
                     update_edge_mlp = counts[0][0] > counts[1][0]
 
+                if sync is not None and not args.conditional:
+                    sync.any_learned(torch.ones(1, dtype=torch.int32, device=learned_out.device))   # keep the collective in lock-step
                 if update_edge_mlp:
                     condtional_update += 1
                     loss = _ce(criterion, learned_out, batch)
@@ -164,14 +170,16 @@ def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edg
                         loss = loss + reg
                     loss.backward()
                     if sync is not None:
-                        sync.sync(True)
+                        sync.sync()
                     optimizer_edge_prob.step()
                     optimizer_gnn.step()
                 else:
                     loss = _ce(criterion, random_out, batch)
                     loss.backward()
-                    if sync is not None and sync.sync(False):
-                        optimizer_edge_prob.step()          # another rank's gate chose "learned"
+                    if sync is not None:
+                        sync.sync()
+                        if any_learned:
+                            optimizer_edge_prob.step()      # another rank's gate chose "learned"
                     optimizer_gnn.step()
 
                 if trace is not None:
@@ -184,8 +192,13 @@ def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edg
                 out = model(batch, batch.edge_index)
                 loss = _ce(criterion, out, batch)
                 loss.backward()
-                if sync is not None and sync.sync(False):
-                    optimizer_edge_prob.step()
+                if sync is not None:
+                    # every rank is in lock-step on the partition stream, so ranks whose partition is small
+                    # (no sampling, no gate) still join the flag all-reduce and the gradient all-reduce
+                    flag = sync.any_learned(torch.zeros(1, dtype=torch.int32, device=out.device))
+                    sync.sync()
+                    if int(flag.item()) > 0:
+                        optimizer_edge_prob.step()
                 optimizer_gnn.step()
 
         elif mode == 'random':

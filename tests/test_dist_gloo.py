@@ -36,12 +36,19 @@ def _worker(rank, world, port, q):
         lin.bias.grad = torch.full((3,), 10.0 * (rank + 1))
         if rank == 0:
             extra.grad = torch.ones(4)
-        any_learned = sync.sync(learned_flag=(rank == 0))
+        any_learned = int(sync.any_learned(torch.tensor([1 if rank == 0 else 0], dtype=torch.int32)).item()) > 0
+        sync.sync()
         ok = (any_learned is True
               and torch.allclose(lin.weight.grad, torch.full((3, 5), 1.5))
               and torch.allclose(lin.bias.grad, torch.full((3,), 15.0))
-              and torch.allclose(extra.grad, torch.full((4,), 0.5)))
-        none_learned = sync.sync(learned_flag=False)
+              and torch.allclose(extra.grad, torch.full((4,), 0.5))
+              and lin.weight.grad.data_ptr() == sync.views[0].data_ptr())
+        # second step: grads already live in the bucket views for some params, fresh tensors for others
+        lin.weight.grad = None
+        lin.bias.grad = torch.full((3,), float(rank))
+        sync.sync()
+        ok = ok and torch.allclose(lin.weight.grad, torch.zeros(3, 5)) and torch.allclose(lin.bias.grad, torch.full((3,), 0.5))
+        none_learned = int(sync.any_learned(torch.zeros(1, dtype=torch.int32)).item()) > 0
         q.put((rank, bool(ok), bool(none_learned)))
     finally:
         dist.destroy_process_group()
