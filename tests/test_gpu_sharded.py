@@ -111,3 +111,56 @@ def test_sharded_draw_and_forward_are_rank_count_invariant():
         assert torch.equal(torch.cat([pt["fwd"]["mask"] for pt in parts]), base["mask"])
         for pt in parts:
             torch.testing.assert_close(pt["fwd"]["out"], base["out"], rtol=1e-4, atol=1e-5)
+
+
+def _dp_worker(rank, world, port, q_out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import contextlib
+        import io
+        import sgs_gnn_amd as S
+        S.fix_seeds(100 + rank)                                   # different noise / dropout streams per rank
+        torch.manual_seed(0)                                      # identical initial replicas
+        m = S.GNNModel(12, 32, 5, dropout_prob=0.3, edge_mlp_type="GCN").to(DEV)
+        opt_gnn = torch.optim.Adam([p for n, p in m.named_parameters() if "gcn" in n], lr=1e-2)
+        opt_edge = torch.optim.Adam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-2)
+        opt_all = torch.optim.Adam(m.parameters(), lr=1e-2)
+        # rank-specific partitions, one of them too small to be sampled (E <= q): exercises every sync branch
+        sizes = [6000, 900, 5000] if rank == 0 else [5500, 7000, 800]
+        batches = [S.synthetic_graph(300, e, 12, 5, seed=10 * rank + i, train_frac=0.5, device=DEV) for i, e in enumerate(sizes)]
+        args = argparse.Namespace(device=DEV, mode="learned", pipeline="hybrid", conditional=True, sparse_edge_mlp=True, t_init=0.7,
+                                  t_min=0.5, degree_bias_coef=0.3, reg1=True, reg2=True, regularizer1_coef=1.0,
+                                  consist_reg_coef=0.5, hybrid_checkpoint=False)
+        with contextlib.redirect_stdout(io.StringIO()):
+            for ep in range(4):
+                ret = S.train(args, ep, 4, m, opt_gnn, opt_edge, opt_all, torch.nn.CrossEntropyLoss(), batches, q=1000)
+        q_out.put((rank, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, ret[2], ret[3]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_train_keeps_replicas_identical():
+    """N > 1 on the partition stream: per-rank batches, one flat gradient all-reduce per step, the scorer's
+    optimiser steps on every rank iff any rank's gate chose 'learned' -> replicas remain bit-identical."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, sd, cond, tot = q.get(timeout=300)
+        got[rank] = (sd, cond, tot)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert got[0][2] == got[1][2] == 3
+    for k in got[0][0]:
+        a, b = torch.from_numpy(got[0][0][k]), torch.from_numpy(got[1][0][k])
+        assert torch.equal(a, b), k
+        assert bool(torch.isfinite(a).all())
