@@ -66,7 +66,7 @@ def kernel_roofline(S, model, batch, reps):
     W1, b1, w2, b2 = sc.fc1.weight.detach().contiguous(), sc.fc1.bias.detach(), sc.fc2.weight.detach().reshape(-1).contiguous(), sc.fc2.bias.detach()
 
     def launch():
-        S._lib.check(L.sgs_edge_score_fwd(codes.data_ptr(), U.data_ptr(), N_NODES, H, batch.edge_index.data_ptr(), E, W1.data_ptr(),
+        S._lib.check(L.sgs_edge_score_fwd(codes.data_ptr(), U.data_ptr(), N_NODES, H, batch.edge_index.data_ptr(), E, 0, W1.data_ptr(),
                                           b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), 0.3, 1, 2, out.data_ptr(), ws.data_ptr(),
                                           ws.numel(), torch.cuda.current_stream().cuda_stream), "edge_score_fwd")
     for _ in range(3):

@@ -198,6 +198,17 @@ int sgs_gcn_norm_bwd(const float* w, const float* gw_hat, const float* gloop, in
                      const int32_t* loop_eid, const int64_t* edge_index, float* dw, void* ws, size_t ws_bytes,
                      sgs_stream_t stream);
 
+/* Split form of sgs_gcn_norm_bwd for edge-sharded graphs: Hn (per node) is linear in the edge contributions, so
+ * each rank computes its partial Hn (gloop non-zero only on the rank that owns the self-loop term), the host
+ * all-reduces Hn [N], and the per-edge pass finishes locally. */
+int sgs_gcn_norm_bwd_node(const float* w, const float* gw_hat, const float* gloop, int64_t n_edges, int64_t N,
+                          const float* dis, const float* loopw, const int32_t* in_ptr, const int32_t* in_src,
+                          const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
+                          float* Hn, sgs_stream_t stream);
+int sgs_gcn_norm_bwd_edge(const float* gw_hat, const float* gloop, int64_t n_edges, int64_t N, const float* dis,
+                          const int32_t* loop_eid, const int64_t* edge_index, const float* Hn, float* dw,
+                          sgs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * K5: weighted CSR SpMM with fused epilogue (GCNConv propagate + bias, F.relu, nn.Dropout;
  * model.py:107-111,159-161):
@@ -235,7 +246,8 @@ int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, void* ws, size_
  * library GEMM done by the caller, so the per-edge contraction is H x H; it runs on the f32
  * matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
  *   codes, U [N,H] f32; W1 = fc1.weight [H,2H]; b1 [H]; w2 = fc2.weight [H]; b2 [1].
- *   4 <= H <= 256, H % 4 == 0.  Dropout on the hidden layer is counter-based, row = edge id.
+ *   4 <= H <= 256, H % 4 == 0.  Dropout on the hidden layer is counter-based, row = edge_id_offset + local
+ *   edge id (edge_id_offset = 0 unless the edge list is a shard of a larger graph).
  * ws: sgs_edge_score_workspace_bytes(N, H).
  *
  * sgs_edge_score_bwd_core runs over an explicit list of active edges (hybrid / two-pass: the q
@@ -255,10 +267,11 @@ int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, void* ws, size_
 size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H);
 void sgs_edge_score_set_variant(int variant);   /* 0 = LDS-tiled, 1 = register-streaming forward (default); benchmarking switch */
 int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
-                       const float* W1, const float* b1, const float* w2, const float* b2, float p_drop,
-                       uint64_t seed, uint32_t site, float* p_out, void* ws, size_t ws_bytes, sgs_stream_t stream);
+                       int64_t edge_id_offset, const float* W1, const float* b1, const float* w2, const float* b2,
+                       float p_drop, uint64_t seed, uint32_t site, float* p_out, void* ws, size_t ws_bytes,
+                       sgs_stream_t stream);
 int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index,
-                            int64_t E, const int64_t* active_eid, int64_t n_active, const float* grad_p,
+                            int64_t E, int64_t edge_id_offset, const int64_t* active_eid, int64_t n_active, const float* grad_p,
                             const float* W1, const float* b1, const float* w2, const float* b2, float p_drop,
                             uint64_t seed, uint32_t site, float* dv, float* hdz, float* dz, float* feat, void* ws,
                             size_t ws_bytes, sgs_stream_t stream);
@@ -296,9 +309,15 @@ size_t sgs_edge_reg_workspace_bytes(int64_t q);
 int sgs_edge_reg_fwd(const float* w, const int64_t* sampled_edge_index, int64_t q, const float* logits, int64_t N,
                      int64_t C, const int64_t* y, const uint8_t* train_mask, float coef1, float coef2, float* out,
                      float* cos_out, void* ws, size_t ws_bytes, sgs_stream_t stream);
-int sgs_edge_reg_bwd(const float* w, const int64_t* sampled_edge_index, int64_t q, const float* logits, int64_t N,
-                     int64_t C, const int64_t* y, const uint8_t* train_mask, const float* out, float coef1,
+int sgs_edge_reg_bwd(const float* w, const int64_t* sampled_edge_index, int64_t q, int64_t q_global, const float* logits,
+                     int64_t N, int64_t C, const int64_t* y, const uint8_t* train_mask, const float* out, float coef1,
                      float coef2, const float* grad_loss, float* dw, float* Gs, float* Gd, sgs_stream_t stream);
+/* Edge-sharded losses: raw[4] = {sum bce, sum (w-cos)^2, #valid, sum labels} over THIS rank's sampled edges; the
+ * ranks all-reduce raw, form reg1 / reg2 with the global q, and call sgs_edge_reg_bwd with out[2], out[3] = the
+ * global #valid / label sum and q_global = the global number of sampled edges (q_global = q when unsharded). */
+int sgs_edge_reg_partial(const float* w, const int64_t* sampled_edge_index, int64_t q, const float* logits, int64_t N,
+                         int64_t C, const int64_t* y, const uint8_t* train_mask, float* raw, void* ws, size_t ws_bytes,
+                         sgs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K8: GAT attention (PyG 2.3.1 GATConv, heads = 1; model.py:189-208 via torch_geometric's GAT):

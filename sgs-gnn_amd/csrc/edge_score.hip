@@ -49,6 +49,7 @@ struct ScoreArgs {
     const int64_t* dst;      // [E]
     const int64_t* active;   // [n] edge ids (backward) or nullptr = identity
     int64_t n;               // rows processed (E forward, n_active backward)
+    int64_t row_offset;      // global id of local edge 0 (edge-sharded graphs): dropout rows are global edge ids
     int H;
     const float* WaT;        // [H][H] k-major
     const float* b1;
@@ -192,7 +193,7 @@ __global__ void __launch_bounds__(kT, 3) edge_score_kernel(ScoreArgs a) {
     const int64_t r = row0 + el;
     const bool live = r < a.n;
     const int64_t eg_id = live ? (a.active ? a.active[r] : r) : 0;   // global edge id: dropout row
-    const uint32_t rkey = dropout_row_key(a.seed, a.site, static_cast<uint64_t>(eg_id));
+    const uint32_t rkey = dropout_row_key(a.seed, a.site, static_cast<uint64_t>(a.row_offset + eg_id));
     const float* Us = a.U + static_cast<int64_t>(s_idx[el]) * H;
     const float* Ud = a.U + static_cast<int64_t>(d_idx[el]) * H;
     float z = 0.f;
@@ -353,7 +354,7 @@ __global__ void __launch_bounds__(kT, 3) edge_score_stream_kernel(ScoreArgs a, c
 
     // ---- epilogue (same as the tiled kernel): hidden unit hh*H/2 + 32t + (q&3) + 8(q>>2) + 4kh
     const int Hrt = a.H;
-    const uint32_t rkey = dropout_row_key(a.seed, a.site, static_cast<uint64_t>(eg_id));
+    const uint32_t rkey = dropout_row_key(a.seed, a.site, static_cast<uint64_t>(a.row_offset + eg_id));
     const float* Us = a.U + static_cast<int64_t>(s) * H;
     const float* Ud = a.U + static_cast<int64_t>(d) * H;
     float z = 0.f;
@@ -557,8 +558,8 @@ static int g_score_variant = 1;
 void sgs_edge_score_set_variant(int v) { g_score_variant = v; }
 
 int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
-                       const float* W1, const float* b1, const float* w2, const float* b2, float p_drop, uint64_t seed,
-                       uint32_t site, float* p_out, void* ws, size_t ws_bytes, sgs_stream_t stream_) {
+                       int64_t edge_id_offset, const float* W1, const float* b1, const float* w2, const float* b2, float p_drop,
+                       uint64_t seed, uint32_t site, float* p_out, void* ws, size_t ws_bytes, sgs_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (int rc = check_common("sgs_edge_score_fwd", N, H, E, p_drop)) return rc;
     if (E == 0) return SGS_OK;
@@ -569,6 +570,7 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
     float* Ceo = cv.take<float>(static_cast<size_t>(N) * H);
     ScoreArgs a{};
     a.codes = codes; a.U = U; a.src = edge_index; a.dst = edge_index + E; a.active = nullptr; a.n = E; a.H = static_cast<int>(H);
+    a.row_offset = edge_id_offset;
     a.WaT = WaT; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.drop_scale = 1.0f / (1.0f - p_drop); a.drop_thresh = dropout_thresh(p_drop); a.seed = seed; a.site = site;
     a.use_drop = p_drop > 0.f; a.p_out = p_out;
@@ -589,7 +591,7 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
 /* Backward core over the active rows: recomputes the hidden layer and writes
  * dv [n,H] = dL/d(fc1 pre-activation), hdz [n,H] = dz * hidden, dz [n], feat [n,H] = x_s*x_d. */
 int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
-                            const int64_t* active_eid, int64_t n_active, const float* grad_p, const float* W1,
+                            int64_t edge_id_offset, const int64_t* active_eid, int64_t n_active, const float* grad_p, const float* W1,
                             const float* b1, const float* w2, const float* b2, float p_drop, uint64_t seed, uint32_t site,
                             float* dv, float* hdz, float* dz, float* feat, void* ws, size_t ws_bytes,
                             sgs_stream_t stream_) {
@@ -606,6 +608,7 @@ int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64
     hipLaunchKernelGGL(transpose_w1a, dim3(cdiv(H, 32), cdiv(H, 32)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);
     ScoreArgs a{};
     a.codes = codes; a.U = U; a.src = edge_index; a.dst = edge_index + E; a.active = active_eid; a.n = n_active;
+    a.row_offset = edge_id_offset;
     a.H = static_cast<int>(H); a.WaT = WaT; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.drop_scale = 1.0f / (1.0f - p_drop); a.drop_thresh = dropout_thresh(p_drop); a.seed = seed; a.site = site;
     a.use_drop = p_drop > 0.f; a.gp = grad_p; a.dv = dv; a.hdz = hdz; a.dz = dz; a.feat = feat;

@@ -822,6 +822,34 @@ int sgs_gcn_norm_bwd(const float* w, const float* gw_hat, const float* gloop, in
     return SGS_OK;
 }
 
+/* Edge-sharded gcn_norm backward: the per-node term Hn is linear in its edge contributions, so each rank
+ * computes its partial (gloop only on the rank that owns the self-loop term), the host all-reduces Hn, and
+ * the per-edge pass finishes locally. */
+int sgs_gcn_norm_bwd_node(const float* w, const float* gw_hat, const float* gloop, int64_t n_edges, int64_t N, const float* dis,
+                          const float* loopw, const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid,
+                          const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid, float* Hn,
+                          sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && n_edges >= 0, SGS_EINVAL, "sgs_gcn_norm_bwd_node: bad sizes");
+    if (N == 0) return SGS_OK;
+    SGS_REQUIRE(w && gw_hat && gloop && dis && loopw && Hn, SGS_EINVAL, "sgs_gcn_norm_bwd_node: null pointer");
+    hipLaunchKernelGGL(norm_bwd_node, dim3(cdiv(N * 64, kT)), dim3(kT), 0, stream, w, gw_hat, gloop, N, in_ptr, in_src, in_eid, out_ptr,
+                       out_dst, out_eid, dis, loopw, Hn);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_gcn_norm_bwd_edge(const float* gw_hat, const float* gloop, int64_t n_edges, int64_t N, const float* dis,
+                          const int32_t* loop_eid, const int64_t* edge_index, const float* Hn, float* dw, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && n_edges >= 0, SGS_EINVAL, "sgs_gcn_norm_bwd_edge: bad sizes");
+    if (n_edges == 0) return SGS_OK;
+    SGS_REQUIRE(gw_hat && gloop && dis && loop_eid && edge_index && Hn && dw, SGS_EINVAL, "sgs_gcn_norm_bwd_edge: null pointer");
+    hipLaunchKernelGGL(norm_bwd_edge, dim3(cdiv(n_edges, kT)), dim3(kT), 0, stream, gw_hat, gloop, edge_index, n_edges, loop_eid, dis, Hn, dw);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
 int sgs_spmm_csr(const float* X, int64_t N, int64_t D, int64_t nnz, const int32_t* ptr, const int32_t* col, const float* val,
                  const float* diag, const float* bias, int act, float p_drop, uint64_t seed, uint32_t site, float* Y,
                  sgs_stream_t stream_) {

@@ -163,12 +163,24 @@ __global__ void __launch_bounds__(kT) reg_fwd_final(const float* __restrict__ pa
     }
 }
 
+// raw[0..3] = {sum bce, sum (w-cos)^2, #valid, sum labels} of this rank's edges (edge-sharded losses: the
+// ranks all-reduce these four sums and finish the formulas with the global q).
+__global__ void __launch_bounds__(kT) reg_raw_final(const float* __restrict__ part, int64_t nblk, float* __restrict__ raw) {
+    __shared__ float red[kT / 64];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int64_t b = threadIdx.x; b < nblk; b += kT) {
+        a0 += part[4 * b]; a1 += part[4 * b + 1]; a2 += part[4 * b + 2]; a3 += part[4 * b + 3];
+    }
+    const float r0 = block_sum(a0, red), r1 = block_sum(a1, red), r2 = block_sum(a2, red), r3 = block_sum(a3, red);
+    if (threadIdx.x == 0) { raw[0] = r0; raw[1] = r1; raw[2] = r2; raw[3] = r3; }
+}
+
 // Per sampled edge: dw[j] and the gradient rows wrt logits[src] (Gs) and logits[dst] (Gd).
 __global__ void __launch_bounds__(kT) reg_bwd_edges(const float* __restrict__ w, const int64_t* __restrict__ sei, int64_t q,
                                                    const float* __restrict__ logits, int64_t C, const int64_t* __restrict__ y,
                                                    const uint8_t* __restrict__ tm, const float* __restrict__ out, float coef1,
-                                                   float coef2, const float* __restrict__ grad_loss, float* __restrict__ dw,
-                                                   float* __restrict__ Gs, float* __restrict__ Gd) {
+                                                   float coef2, float q_norm, const float* __restrict__ grad_loss,
+                                                   float* __restrict__ dw, float* __restrict__ Gs, float* __restrict__ Gd) {
     const int64_t j = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
     if (j >= q) return;
     const float gl = grad_loss[0];
@@ -180,7 +192,7 @@ __global__ void __launch_bounds__(kT) reg_bwd_edges(const float* __restrict__ w,
     const float inv = 1.0f / sqrtf(den2);
     const float cs = t.dot * inv;
     const float wj = w[j];
-    const float r = 2.0f * (wj - cs) / static_cast<float>(q) * coef2 * gl;        // dL/d(w - cos)
+    const float r = 2.0f * (wj - cs) / q_norm * coef2 * gl;                        // dL/d(w - cos); q_norm = global #sampled edges
     float g = r;
     if (coef1 != 0.f && out[3] > 1.f && tm[s] && tm[d]) {
         const float tgt = (y[s] == y[d]) ? 1.f : 0.f;
@@ -258,14 +270,34 @@ int sgs_edge_reg_fwd(const float* w, const int64_t* sampled_edge_index, int64_t 
     return SGS_OK;
 }
 
-int sgs_edge_reg_bwd(const float* w, const int64_t* sampled_edge_index, int64_t q, const float* logits, int64_t N, int64_t C,
-                     const int64_t* y, const uint8_t* train_mask, const float* out, float coef1, float coef2,
+int sgs_edge_reg_partial(const float* w, const int64_t* sampled_edge_index, int64_t q, const float* logits, int64_t N, int64_t C,
+                         const int64_t* y, const uint8_t* train_mask, float* raw, void* ws, size_t ws_bytes, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(q >= 0 && N > 0 && C > 0 && raw, SGS_EINVAL, "sgs_edge_reg_partial: bad arguments");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_reg_workspace_bytes(q), SGS_EWORKSPACE, "sgs_edge_reg_partial: workspace too small");
+    Carver cv(ws);
+    const int64_t nblk = cdiv(q, kT);
+    float* part = cv.take<float>(4 * (nblk + 1));
+    if (q > 0) {
+        SGS_REQUIRE(w && sampled_edge_index && logits && y && train_mask, SGS_EINVAL, "sgs_edge_reg_partial: null pointer");
+        hipLaunchKernelGGL(reg_fwd_partial, dim3(nblk), dim3(kT), 0, stream, w, sampled_edge_index, q, logits, C, y, train_mask,
+                           static_cast<float*>(nullptr), part);
+    }
+    hipLaunchKernelGGL(reg_raw_final, dim3(1), dim3(kT), 0, stream, part, nblk, raw);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_edge_reg_bwd(const float* w, const int64_t* sampled_edge_index, int64_t q, int64_t q_global, const float* logits, int64_t N,
+                     int64_t C, const int64_t* y, const uint8_t* train_mask, const float* out, float coef1, float coef2,
                      const float* grad_loss, float* dw, float* Gs, float* Gd, sgs_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    SGS_REQUIRE(q > 0 && N > 0 && C > 0 && w && sampled_edge_index && logits && y && train_mask && out && grad_loss && dw && Gs && Gd,
-                SGS_EINVAL, "sgs_edge_reg_bwd: bad arguments");
+    SGS_REQUIRE(q >= 0 && q_global >= q && N > 0 && C > 0, SGS_EINVAL, "sgs_edge_reg_bwd: bad arguments");
+    if (q == 0) return SGS_OK;
+    SGS_REQUIRE(w && sampled_edge_index && logits && y && train_mask && out && grad_loss && dw && Gs && Gd, SGS_EINVAL,
+                "sgs_edge_reg_bwd: null pointer");
     hipLaunchKernelGGL(reg_bwd_edges, dim3(cdiv(q, kT)), dim3(kT), 0, stream, w, sampled_edge_index, q, logits, C, y, train_mask, out,
-                       coef1, coef2, grad_loss, dw, Gs, Gd);
+                       coef1, coef2, static_cast<float>(q_global), grad_loss, dw, Gs, Gd);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

@@ -339,17 +339,17 @@ def _endpoint_reduce(M_out, M_in, T, graph: Graph, s_out, s_in, H):
 
 class _EdgeScore(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, codes, U, W1, b1, w2, b2, edge_index, active, p, seed, site):
+    def forward(ctx, codes, U, W1, b1, w2, b2, edge_index, active, p, seed, site, edge_id_offset):
         L = _lib.lib()
         N, H = codes.shape
         E = edge_index.shape[1]
         out = torch.empty(E, dtype=torch.float32, device=codes.device)
         ws = workspace(L.sgs_edge_score_workspace_bytes(N, H), codes.device)
         _lib.check(L.sgs_edge_score_fwd(_ptr(codes, torch.float32), _ptr(U, torch.float32), N, H, _ptr(edge_index, torch.int64), E,
-                                        _ptr(W1, torch.float32), _ptr(b1), _ptr(w2), _ptr(b2), float(p), seed, site, _ptr(out),
+                                        edge_id_offset, _ptr(W1, torch.float32), _ptr(b1), _ptr(w2), _ptr(b2), float(p), seed, site, _ptr(out),
                                         ws.data_ptr(), ws.numel(), _stream()), "sgs_edge_score_fwd")
         ctx.save_for_backward(codes, U, W1, b1, w2, b2, edge_index)
-        ctx.active, ctx.p, ctx.seed, ctx.site = active, float(p), seed, site
+        ctx.active, ctx.p, ctx.seed, ctx.site, ctx.offset = active, float(p), seed, site, edge_id_offset
         return out
 
     @staticmethod
@@ -372,7 +372,7 @@ class _EdgeScore(torch.autograd.Function):
         dz = torch.empty(n, **f32)
         if n > 0:
             ws = workspace(L.sgs_edge_score_workspace_bytes(N, H), dev)
-            _lib.check(L.sgs_edge_score_bwd_core(_ptr(codes), _ptr(U), N, H, _ptr(edge_index), E, _ptr(eid), n, _ptr(gp_act),
+            _lib.check(L.sgs_edge_score_bwd_core(_ptr(codes), _ptr(U), N, H, _ptr(edge_index), E, ctx.offset, _ptr(eid), n, _ptr(gp_act),
                                                  _ptr(W1), _ptr(b1), _ptr(w2), _ptr(b2), ctx.p, ctx.seed, ctx.site, _ptr(dv),
                                                  _ptr(hdz), _ptr(dz), _ptr(feat), ws.data_ptr(), ws.numel(), _stream()),
                        "sgs_edge_score_bwd_core")
@@ -384,17 +384,17 @@ class _EdgeScore(torch.autograd.Function):
         db2 = dz.sum().reshape(1)
         dcodes = _endpoint_reduce(dfeat, dfeat, codes, graph, 1.0, 1.0, H)
         dU = _endpoint_reduce(dv, dv, None, graph, 1.0, -1.0, H)
-        return dcodes, dU, dW1, db1, dw2, db2, None, None, None, None, None
+        return dcodes, dU, dW1, db1, dw2, db2, None, None, None, None, None, None
 
 
-def edge_score(codes, fc1_w, fc1_b, fc2_w, fc2_b, edge_index, active=None, p=0.0, seed=0, site=0):
+def edge_score(codes, fc1_w, fc1_b, fc2_w, fc2_b, edge_index, active=None, p=0.0, seed=0, site=0, edge_id_offset=0):
     """K1b.  codes [N,H]; fc1_w [H,2H]; fc1_b [H]; fc2_w [1,H]; fc2_b [1]; edge_index [2,E] -> p [E]."""
     _need_gpu(codes, fc1_w, edge_index)
     H = codes.shape[1]
     U = codes @ fc1_w[:, H:].t()                           # node-level half of fc1 (library GEMM)
     return _EdgeScore.apply(codes.contiguous(), U.contiguous(), fc1_w.contiguous(), fc1_b.contiguous(),
                             fc2_w.reshape(-1).contiguous(), fc2_b.contiguous(), edge_index.contiguous(), active, float(p),
-                            int(seed), int(site))
+                            int(seed), int(site), int(edge_id_offset))
 
 
 # ------------------------------------------------------------------ gate + losses (K6)
@@ -478,7 +478,7 @@ class _EdgeReg(torch.autograd.Function):
         dw = torch.empty(q, dtype=torch.float32, device=dev)
         Gs = torch.empty(q, C, dtype=torch.float32, device=dev)
         Gd = torch.empty(q, C, dtype=torch.float32, device=dev)
-        _lib.check(L.sgs_edge_reg_bwd(_ptr(w), _ptr(sei), q, _ptr(logits), N, C, _ptr(y), _ptr(mask_u8), _ptr(out), ctx.coef1,
+        _lib.check(L.sgs_edge_reg_bwd(_ptr(w), _ptr(sei), q, q, _ptr(logits), N, C, _ptr(y), _ptr(mask_u8), _ptr(out), ctx.coef1,
                                       ctx.coef2, _ptr(g), _ptr(dw), _ptr(Gs), _ptr(Gd), _stream()), "sgs_edge_reg_bwd")
         dlogits = _endpoint_reduce(Gs, Gd, None, ctx.graph, 1.0, 1.0, C) if ctx.coef2 != 0.0 else None
         return dw, dlogits, None, None, None, None, None, None, None

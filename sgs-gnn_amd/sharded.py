@@ -13,10 +13,12 @@ whose boundaries are multiples of the sampler chunk (2048).  Per rank and step:
     all-reduce of node embeddings over xGMI" of the north star); degrees are all-reduced once per graph;
     bias / ReLU / dropout run after the all-reduce on every rank (replicated).
 
-Scope this round: the forward / inference path (`sharded_evaluate_forward`, i.e. evaluate.py's learned
-mode on a graph too large for one GPU).  The training backward needs the matching gradient all-reduces
-(Megatron-style f/g operators at the shard boundaries) and is not built yet.
-Collectives go through torch.distributed: backend "nccl" is RCCL on ROCm; tests use gloo.
+Built: the inference path (`sharded_evaluate_forward` = evaluate.py's learned mode) and the hybrid TRAINING
+step (`train_step_sharded`): replicated tensors enter sharded compute through `_F` (identity forward,
+all-reduce backward) and partial results leave through `_G` (all-reduce forward, identity backward), the
+gcn_norm backward's per-node term and the regulariser sums are all-reduced, so every rank finishes backward
+with complete, identical gradients and no separate gradient synchronisation is needed.
+Collectives go through torch.distributed: backend "nccl" is RCCL on ROCm; tests use gloo (R processes on one GPU).
 """
 from __future__ import annotations
 
@@ -203,3 +205,230 @@ def sharded_evaluate_forward(args, model, shard: EdgeShard, q: int, noise_local=
     h1 = sharded_propagate(x @ model.gcn1.lin.weight.t(), nms, model.gcn1.bias, act=ops.ACT_RELU)
     out = sharded_propagate(h1 @ model.gcn2.lin.weight.t(), nms, model.gcn2.bias)
     return out, smp
+
+
+# ======================================================================================================
+# Edge-sharded TRAINING step (hybrid pipeline).  Replicated tensors enter sharded compute through `_F`
+# (identity forward, all-reduce backward) and partial results leave it through `_G` (all-reduce forward,
+# identity backward), so every rank ends the backward pass with complete, identical parameter gradients
+# and the replicas stay in lock-step without a separate gradient synchronisation.
+# ======================================================================================================
+class _F(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        if _world()[1] > 1:
+            g = g.clone()
+            dist.all_reduce(g)
+        return g
+
+
+class _G(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = x.clone()
+        if _world()[1] > 1:
+            dist.all_reduce(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _BiasAct(torch.autograd.Function):
+    """Replicated layer epilogue after the embedding all-reduce: Y = act(X + bias)."""
+
+    @staticmethod
+    def forward(ctx, X, bias, act, p, seed, site):
+        L = _lib.lib()
+        N, D = X.shape
+        Y = torch.empty_like(X)
+        _lib.check(L.sgs_bias_act(ops._ptr(X.contiguous()), ops._ptr(bias), N, D, act, float(p), seed, site, ops._ptr(Y), ops._stream()),
+                   "sgs_bias_act")
+        ctx.act, ctx.p, ctx.has_bias = act, float(p), bias is not None
+        ctx.save_for_backward(Y if act != ops.ACT_NONE else None)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        L = _lib.lib()
+        (Y,) = ctx.saved_tensors
+        dY = dY.contiguous()
+        if ctx.act != ops.ACT_NONE:
+            dZ = torch.empty_like(dY)
+            _lib.check(L.sgs_act_bwd(ops._ptr(dY), ops._ptr(Y), dY.numel(), ctx.act, ctx.p, ops._ptr(dZ), ops._stream()), "sgs_act_bwd")
+        else:
+            dZ = dY
+        return dZ, (ops._colsum(dZ) if ctx.has_bias else None), None, None, None, None
+
+
+class _ShardedNorm(torch.autograd.Function):
+    """gcn_norm over the union of all ranks' edges, differentiable wrt this rank's edge weights."""
+
+    @staticmethod
+    def forward(ctx, w, graph, box):
+        nm = sharded_norm(graph, w)
+        if _world()[0] != 0:
+            nm.what_loop = None                      # the self-loop term is added (and differentiated) on rank 0 only
+        box.append(nm)
+        ctx.nm = nm
+        return torch.empty(graph.n_edges + graph.N, dtype=torch.float32, device=w.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        nm, gr = ctx.nm, ctx.nm.graph
+        rank, world = _world()
+        g = g.contiguous()
+        n, N = gr.n_edges, gr.N
+        gw = g[:n].contiguous() if n > 0 else torch.zeros(1, dtype=torch.float32, device=g.device)
+        gl = g[n:].contiguous() if rank == 0 else torch.zeros(N, dtype=torch.float32, device=g.device)
+        Hn = torch.empty(N, dtype=torch.float32, device=g.device)
+        wv = nm.w if n > 0 else torch.zeros(1, dtype=torch.float32, device=g.device)
+        _lib.check(L.sgs_gcn_norm_bwd_node(ops._ptr(wv), ops._ptr(gw), ops._ptr(gl), n, N, ops._ptr(nm.dis), ops._ptr(nm.loopw),
+                                           ops._ptr(gr.in_ptr), ops._ptr(gr.in_src), ops._ptr(gr.in_eid), ops._ptr(gr.out_ptr),
+                                           ops._ptr(gr.out_dst), ops._ptr(gr.out_eid), ops._ptr(Hn), ops._stream()), "sgs_gcn_norm_bwd_node")
+        if world > 1:
+            dist.all_reduce(Hn)
+        dw = torch.empty(n, dtype=torch.float32, device=g.device)
+        if n > 0:
+            _lib.check(L.sgs_gcn_norm_bwd_edge(ops._ptr(gw), ops._ptr(gl), n, N, ops._ptr(nm.dis), ops._ptr(gr.loop_eid),
+                                               ops._ptr(gr.edge_index), ops._ptr(Hn), ops._ptr(dw), ops._stream()), "sgs_gcn_norm_bwd_edge")
+        return dw, None, None
+
+
+def sharded_norm_autograd(graph, w):
+    rank, _ = _world()
+    if w is None or not (w.requires_grad and torch.is_grad_enabled()):
+        nm = sharded_norm(graph, None if w is None else w.detach().contiguous())
+        if rank != 0:
+            nm.what_loop = None
+        return nm
+    box = []
+    handle = _ShardedNorm.apply(w.contiguous(), graph, box)
+    nm = box[0]
+    nm.handle = handle
+    return nm
+
+
+def sharded_gcn_layer(x, W, bias, nm, act=ops.ACT_NONE, p=0.0, seed=0, site=0):
+    """One GCN layer on an edge-sharded graph with autograd: replicated X W^T -> f -> local aggregate -> g -> epilogue."""
+    xl = _F.apply(ops.linear_nobias(x, W))
+    part = ops._Propagate.apply(xl.contiguous(), nm.handle, None, nm, ops.ACT_NONE, 0.0, 0, 0)
+    return _BiasAct.apply(_G.apply(part), bias, act, float(p), int(seed), int(site))
+
+
+class _ShardedEdgeReg(torch.autograd.Function):
+    """coef1 * reg1 + coef2 * reg2 over the union of all ranks' sampled edges."""
+
+    @staticmethod
+    def forward(ctx, w, logits, sei, y, mask_u8, graph, coef1, coef2, q_global):
+        L = _lib.lib()
+        q = w.numel()
+        N, C = logits.shape
+        dev = w.device
+        raw = torch.empty(4, dtype=torch.float32, device=dev)
+        ws = ops.workspace(L.sgs_edge_reg_workspace_bytes(q), dev)
+        _lib.check(L.sgs_edge_reg_partial(ops._ptr(w), ops._ptr(sei), q, ops._ptr(logits), N, C, ops._ptr(y), ops._ptr(mask_u8),
+                                          ops._ptr(raw), ws.data_ptr(), ws.numel(), ops._stream()), "sgs_edge_reg_partial")
+        if _world()[1] > 1:
+            dist.all_reduce(raw)
+        reg1 = torch.where(raw[3] > 1.0, raw[0] / raw[2], torch.zeros((), device=dev))          # training_hybrid.py:125-128
+        reg2 = raw[1] / float(q_global)
+        out = torch.stack([reg1, reg2, raw[2], raw[3], coef1 * reg1 + coef2 * reg2]).contiguous()
+        ctx.save_for_backward(w, logits, sei, y, mask_u8, out)
+        ctx.graph, ctx.coef1, ctx.coef2, ctx.q_global = graph, float(coef1), float(coef2), int(q_global)
+        return out[4].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        w, logits, sei, y, mask_u8, out = ctx.saved_tensors
+        q = w.numel()
+        N, C = logits.shape
+        dev = w.device
+        g = g.reshape(1).contiguous().float()
+        dw = torch.empty(q, dtype=torch.float32, device=dev)
+        Gs = torch.empty(max(q, 1), C, dtype=torch.float32, device=dev)
+        Gd = torch.empty(max(q, 1), C, dtype=torch.float32, device=dev)
+        _lib.check(L.sgs_edge_reg_bwd(ops._ptr(w), ops._ptr(sei), q, ctx.q_global, ops._ptr(logits), N, C, ops._ptr(y), ops._ptr(mask_u8),
+                                      ops._ptr(out), ctx.coef1, ctx.coef2, ops._ptr(g), ops._ptr(dw), ops._ptr(Gs), ops._ptr(Gd),
+                                      ops._stream()), "sgs_edge_reg_bwd")
+        dlogits = ops._endpoint_reduce(Gs, Gd, None, ctx.graph, 1.0, 1.0, C)       # partial: the caller's _F all-reduces it
+        return dw, dlogits, None, None, None, None, None, None, None
+
+
+def train_step_sharded(args, model, shard: EdgeShard, optimizer_gnn, optimizer_edge_prob, criterion, q: int, noise=None):
+    """One hybrid step (training_hybrid.py:35-141, mode 'learned', E > q, EdgeProbGCN scorer) on an edge-sharded
+    graph.  Dropout seeds / noise ticks are consumed in the same order as the single-GPU `train`, rows are
+    global ids, so the result matches the unsharded step up to fp32 summation order.  Returns a trace dict."""
+    from .model import _DropoutClock
+    from .sampling import _NoiseClock
+    noise = noise or {}
+    model.train()
+    optimizer_edge_prob.zero_grad()
+    optimizer_gnn.zero_grad()
+    sc = model.edge_prob_mlp
+    x, N, ei = shard.x, shard.N, shard.edge_index
+    p = sc.dropout.p
+    act = ops.ACT_RELU_DROPOUT if p > 0 else ops.ACT_RELU
+    off, bounds = shard.edge_offset, shard.bounds
+
+    # K0: prior-only draw (global), this rank's random edges
+    seed_n, tick = (0, 0) if noise.get("prior") is not None else _NoiseClock.next()
+    rs = dist_sample_topq(ops.SAMPLE_PRIOR, shard.prob, None, 0.0, q, ei, off, bounds, noise_local=noise.get("prior"), seed=seed_n,
+                          stream_id=tick)
+    g_r = ops.get_graph(rs.edge_index, N)
+    nm_r = sharded_norm_autograd(g_r, None)
+    # scorer encoder over the random graph (model.py:106-108)
+    h = sharded_gcn_layer(x, sc.gcn1.lin.weight, sc.gcn1.bias, nm_r, act=act, p=p, seed=_DropoutClock.next_seed(), site=SITE_ENC)
+    codes = sharded_gcn_layer(h, sc.gcn2.lin.weight, sc.gcn2.bias, nm_r, act=ops.ACT_RELU)
+    # scores for this rank's edges; replicated inputs pass through f so their partial gradients are summed
+    active = ops.ActiveSet()
+    p_local = ops.edge_score(_F.apply(codes), _F.apply(sc.fc1.weight), _F.apply(sc.fc1.bias), _F.apply(sc.fc2.weight),
+                             _F.apply(sc.fc2.bias), ei, active=active, p=p, seed=_DropoutClock.next_seed(), site=SITE_SCORE,
+                             edge_id_offset=off)
+    # K2+K3: learned draw (global)
+    seed_n, tick = (0, 0) if noise.get("sample") is not None else _NoiseClock.next()
+    smp = dist_sample_topq(ops.SAMPLE_LEARNED, p_local, shard.prob, args.degree_bias_coef, q, ei, off, bounds,
+                           noise_local=noise.get("sample"), seed=seed_n, stream_id=tick)
+    local_ids = smp.eid - off
+    g_s = ops.get_graph(smp.edge_index, N)
+    active.set(local_ids, g_s)
+    w_local = p_local.index_select(0, local_ids)
+    nm_s = sharded_norm_autograd(g_s, w_local)
+    pg = model.dropout.p
+    actg = ops.ACT_RELU_DROPOUT if pg > 0 else ops.ACT_RELU
+    h1 = sharded_gcn_layer(x, model.gcn1.lin.weight, model.gcn1.bias, nm_s, act=actg, p=pg, seed=_DropoutClock.next_seed(), site=SITE_GNN)
+    learned_out = sharded_gcn_layer(h1, model.gcn2.lin.weight, model.gcn2.bias, nm_s)
+    update_edge_mlp, random_out, counts = True, None, None
+    if args.conditional:
+        h1r = sharded_gcn_layer(x, model.gcn1.lin.weight, model.gcn1.bias, nm_r, act=actg, p=pg, seed=_DropoutClock.next_seed(),
+                                site=SITE_GNN)
+        random_out = sharded_gcn_layer(h1r, model.gcn2.lin.weight, model.gcn2.bias, nm_r)
+        cbuf = torch.empty(4, dtype=torch.int32, device=x.device)
+        ops.masked_correct(learned_out, shard.y, shard.train_mask, out=cbuf[0:2])
+        ops.masked_correct(random_out, shard.y, shard.train_mask, out=cbuf[2:4])
+        counts = cbuf.tolist()
+        update_edge_mlp = counts[0] > counts[2]                  # logits are replicated: every rank takes the same branch
+    if update_edge_mlp:
+        loss = ops.masked_cross_entropy(learned_out, shard.y, shard.train_mask)
+        c1 = args.regularizer1_coef if args.reg1 else 0.0
+        c2 = args.consist_reg_coef if args.reg2 else 0.0
+        if c1 != 0.0 or c2 != 0.0:
+            loss = loss + _ShardedEdgeReg.apply(w_local.contiguous(), _F.apply(learned_out).contiguous(), smp.edge_index, shard.y,
+                                                ops._u8(shard.train_mask), g_s, float(c1), float(c2), q)
+        loss.backward()
+        optimizer_edge_prob.step()
+        optimizer_gnn.step()
+    else:
+        loss = ops.masked_cross_entropy(random_out, shard.y, shard.train_mask)
+        loss.backward()
+        optimizer_gnn.step()
+    return dict(loss=loss.detach(), sample=smp, random=rs, update_edge_mlp=update_edge_mlp, learned_out=learned_out.detach(),
+                counts=counts)

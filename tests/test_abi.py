@@ -49,7 +49,7 @@ def test_argument_validation_reports_through_error_channel(pkg):
     L = pkg._lib.lib()
     rc = L.sgs_sample_topq(0, None, None, 0.3, None, 0, 0, 10, 11, None, None, None, None, None, None, None, None, 0, None)
     assert rc == -1 and b"without replacement" in L.sgs_last_error()
-    rc = L.sgs_edge_score_fwd(None, None, 10, 300, None, 5, None, None, None, None, 0.0, 0, 0, None, None, 0, None)
+    rc = L.sgs_edge_score_fwd(None, None, 10, 300, None, 5, 0, None, None, None, None, 0.0, 0, 0, None, None, 0, None)
     assert rc == -1 and b"unsupported" in L.sgs_last_error()
 
 

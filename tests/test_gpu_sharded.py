@@ -164,3 +164,97 @@ def test_data_parallel_train_keeps_replicas_identical():
         a, b = torch.from_numpy(got[0][0][k]), torch.from_numpy(got[1][0][k])
         assert torch.equal(a, b), k
         assert bool(torch.isfinite(a).all())
+
+
+def _train_setup():
+    import sgs_gnn_amd as S
+    b = S.synthetic_graph(300, 21000, 16, 5, seed=3, train_frac=0.5, device=DEV)
+    torch.manual_seed(0)
+    m = S.GNNModel(16, 64, 5, dropout_prob=0.3, edge_mlp_type="GCN").to(DEV)
+    og = torch.optim.Adam([p for n, p in m.named_parameters() if "gcn" in n], lr=1e-3)
+    oe = torch.optim.Adam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-3)
+    args = argparse.Namespace(device=DEV, mode="learned", pipeline="hybrid", conditional=True, sparse_edge_mlp=True, t_init=0.7,
+                              t_min=0.5, degree_bias_coef=0.3, reg1=True, reg2=True, regularizer1_coef=1.0, consist_reg_coef=0.5,
+                              hybrid_checkpoint=False)
+    return S, b, m, og, oe, args
+
+
+def _sharded_train_worker(rank, world, port, q_out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from importlib import import_module
+        S, b, m, og, oe, args = _train_setup()
+        sh = import_module("sgs_gnn_amd.sharded")
+        shard = sh.EdgeShard(b, rank, world)
+        q = b.edge_index.shape[1] // 5
+        S.fix_seeds(5)
+        out = {}
+        for step in range(2):
+            tr = sh.train_step_sharded(args, m, shard, og, oe, torch.nn.CrossEntropyLoss(), q)
+            if step == 0:
+                out["grads"] = {k: (v.grad.detach().cpu().numpy() if v.grad is not None else None) for k, v in m.named_parameters()}
+                out["mask"] = tr["sample"].mask.cpu().numpy()
+                out["rmask"] = tr["random"].mask.cpu().numpy()
+                out["logits"] = tr["learned_out"].cpu().numpy()
+                out["loss0"] = float(tr["loss"])
+                out["upd0"] = bool(tr["update_edge_mlp"])
+        out["params"] = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+        q_out.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_training_step_matches_single_gpu_train():
+    """Config 5 training: f/g operators at the shard boundaries give every rank the complete gradients; the
+    2- and 3-rank steps reproduce the regular single-GPU train() (same seeds: noise and dropout are keyed
+    by global ids) and the replicas are bit-identical to each other."""
+    import contextlib
+    import io
+    S, b, m, og, oe, args = _train_setup()
+    q = b.edge_index.shape[1] // 5
+    S.fix_seeds(5)
+    oa = torch.optim.Adam(m.parameters(), lr=1e-3)
+    args._sgs_trace = tr = {}
+    ref = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        for step in range(2):
+            S.train(args, step, 2, m, og, oe, oa, torch.nn.CrossEntropyLoss(), [b], q=q)
+            if step == 0:
+                ref["grads"] = {k: (v.grad.detach().cpu() if v.grad is not None else None) for k, v in m.named_parameters()}
+                ref["mask"], ref["logits"] = tr["sample"].mask.cpu(), tr["learned_out"].cpu()
+                ref["loss0"], ref["upd0"] = float(tr["loss"]), bool(tr["update_edge_mlp"])
+    ref["params"] = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+
+    for world in (2, 3):
+        ctx = mp.get_context("spawn")
+        qq = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_sharded_train_worker, args=(r, world, port, qq)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = dict(qq.get(timeout=300) for _ in range(world))
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        mask = torch.cat([torch.from_numpy(got[r]["mask"]) for r in range(world)])
+        assert torch.equal(mask, ref["mask"]), world
+        for r in range(world):
+            o = got[r]
+            assert o["upd0"] == ref["upd0"]
+            assert abs(o["loss0"] - ref["loss0"]) < 2e-5
+            torch.testing.assert_close(torch.from_numpy(o["logits"]), ref["logits"], rtol=1e-4, atol=1e-5)
+            for k, g in ref["grads"].items():
+                if g is None:
+                    assert o["grads"][k] is None or float(abs(o["grads"][k]).max()) == 0.0, k
+                else:
+                    a = torch.from_numpy(o["grads"][k])
+                    err = float((a - g).abs().max()) / (float(g.abs().max()) + 1e-12)
+                    assert err < 2e-3, (world, k, err)
+            for k, v in ref["params"].items():                       # two Adam steps: lr-sized moves, compare loosely
+                torch.testing.assert_close(torch.from_numpy(o["params"][k]), v, rtol=0, atol=2.5e-3)
+            for k in o["params"]:                                     # replicas are bit-identical to each other
+                assert (o["params"][k] == got[0]["params"][k]).all(), (world, k)
