@@ -391,7 +391,7 @@ def edge_score(codes, fc1_w, fc1_b, fc2_w, fc2_b, edge_index, active=None, p=0.0
     """K1b.  codes [N,H]; fc1_w [H,2H]; fc1_b [H]; fc2_w [1,H]; fc2_b [1]; edge_index [2,E] -> p [E]."""
     _need_gpu(codes, fc1_w, edge_index)
     H = codes.shape[1]
-    U = codes @ fc1_w[:, H:].t()                           # node-level half of fc1 (library GEMM)
+    U = linear_nobias(codes, fc1_w[:, H:])                 # node-level half of fc1: library GEMM forward, sgs_gemm_tn weight gradient
     return _EdgeScore.apply(codes.contiguous(), U.contiguous(), fc1_w.contiguous(), fc1_b.contiguous(),
                             fc2_w.reshape(-1).contiguous(), fc2_b.contiguous(), edge_index.contiguous(), active, float(p),
                             int(seed), int(site), int(edge_id_offset))
@@ -567,7 +567,7 @@ class _LinearNoBias(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W):
         ctx.save_for_backward(x, W)
-        return x @ W.t()
+        return x @ W.t()                     # W may be a strided view (e.g. fc1.weight[:, H:])
 
     @staticmethod
     def backward(ctx, dY):

@@ -120,10 +120,19 @@ def test_train_straight_through_with_gat_head():
                               t_init=0.7, t_min=0.5, degree_bias_coef=0.3, reg1=True, reg2=True, regularizer1_coef=1.0,
                               consist_reg_coef=0.5)
     S.fix_seeds(0)
+
+    def eval_ce():
+        m.eval()
+        with torch.no_grad():
+            v = float(S.ops.masked_cross_entropy(m(b, b.edge_index), b.y, b.train_mask))
+        m.train()
+        return v
+    before = eval_ce()
     losses = []
     for ep in range(30):
         ret = S.train(args, ep, 30, m, opt_gnn, opt_edge, opt_all, torch.nn.CrossEntropyLoss(), [b], q=q)
         losses.append(ret[0])
     assert all(l == l for l in losses)                                  # finite
-    assert sum(losses[-5:]) / 5 < sum(losses[:5]) / 5                   # it learns
-    assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for n, p in m.named_parameters() if "fc1" in n) or True
+    # the per-step loss mixes two objectives (CE vs CE + regularisers, by gate branch): judge learning by the
+    # eval-mode full-graph cross-entropy on the train nodes instead
+    assert eval_ce() < before - 0.05
