@@ -55,26 +55,28 @@ class GCNConv(nn.Module):
         nn.init.uniform_(self.lin.weight, -a, a)
         nn.init.zeros_(self.bias)
 
-    def _lin(self, x):
-        """x W^T, memoised on (x, W) identity + version: the hybrid step runs GNNModel twice on the same
-        batch.x with the same weights (learned and random forward, training_hybrid.py:88,93)."""
+    def _memo(self, x):
+        """Memoised x W^T (plain tensor, no autograd graph) keyed on (x, W) identity + version: the hybrid step runs
+        GNNModel twice on the same batch.x with the same weights (learned and random forward,
+        training_hybrid.py:88,93); the weight gradient is computed by hand in the layer's backward."""
         W = self.lin.weight
-        key = (x.data_ptr(), x._version, tuple(x.shape), W.data_ptr(), W._version, torch.is_grad_enabled())
+        key = (x.data_ptr(), x._version, tuple(x.shape), W.data_ptr(), W._version)
         c = getattr(self, "_lin_cache", None)
         if c is not None and c[0] == key and c[1]() is x:
-            return c[2]
-        xl = ops.linear_nobias(x, W)
-        import weakref
-        try:
-            self._lin_cache = (key, weakref.ref(x), xl)
-        except TypeError:
-            self._lin_cache = None
-        return xl
+            return c[2], key
+        return None, key
 
     def forward(self, x, edge_index, edge_weight=None, *, norm=None, act=ops.ACT_NONE, p=0.0, seed=0, site=0):
         if norm is None:
             norm = ops.gcn_norm(ops.get_graph(edge_index, x.shape[0]), edge_weight)
-        return ops.gcn_propagate(self._lin(x), norm, self.bias, act=act, p=p, seed=seed, site=site)
+        xl, key = self._memo(x)
+        y, xl = ops.gcn_layer(x, self.lin.weight, self.bias, norm, act=act, p=p, seed=seed, site=site, xl=xl)
+        try:
+            import weakref
+            self._lin_cache = (key, weakref.ref(x), xl)
+        except TypeError:
+            self._lin_cache = None
+        return y
 
 
 class GNNModel(nn.Module):

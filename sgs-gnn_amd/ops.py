@@ -616,3 +616,65 @@ def degree_prior(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
     _lib.check(L.sgs_degree_prior_logits(_ptr(g.edge_index), E, num_nodes, _ptr(g.in_ptr), _ptr(g.out_ptr), _ptr(logits), _stream()),
                "sgs_degree_prior_logits")
     return torch.softmax(logits, dim=0)
+
+
+# ------------------------------------------------------------------ one GCN layer as ONE autograd node
+class _GCNLayer(torch.autograd.Function):
+    """Y = act(A_hat (x W^T) + bias): the node-level product (library GEMM) and the propagation (K5) in a single
+    autograd node -- the step is launch/host-bound at partition scale, so halving the Python nodes per layer matters.
+    `xl` may be supplied (memoised x W^T shared by the learned and the random forward of one step)."""
+
+    @staticmethod
+    def forward(ctx, x, W, handle, bias, nm, act, p, seed, site, xl):
+        gr = nm.graph
+        if xl is None:
+            xl = x @ W.t()
+        N, D = xl.shape
+        Y = _spmm(xl, gr.in_ptr, gr.in_src, nm.what_in, nm.what_loop, bias, act, p, seed, site, N, D, gr.n_edges)
+        ctx.nm, ctx.act, ctx.p = nm, act, p
+        ctx.has_bias, ctx.has_handle = bias is not None, handle is not None
+        ctx.save_for_backward(x, W, xl, Y if act != ACT_NONE else None)
+        ctx.mark_non_differentiable(xl)
+        return Y, xl
+
+    @staticmethod
+    def backward(ctx, dY, _dxl_unused):
+        L = _lib.lib()
+        nm, gr = ctx.nm, ctx.nm.graph
+        x, W, xl, Y = ctx.saved_tensors
+        N, D = xl.shape
+        dY = dY.contiguous()
+        if ctx.act != ACT_NONE:
+            dZ = torch.empty_like(dY)
+            _lib.check(L.sgs_act_bwd(_ptr(dY), _ptr(Y), dY.numel(), ctx.act, float(ctx.p), _ptr(dZ), _stream()), "sgs_act_bwd")
+        else:
+            dZ = dY
+        dx = dW = g = dbias = None
+        need_x, need_W = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if need_x or need_W:
+            dxl = _spmm(dZ, gr.out_ptr, gr.out_dst, nm.what_out, nm.what_loop, None, ACT_NONE, 0.0, 0, 0, N, D, gr.n_edges)
+            if need_W:
+                K, M, Nn = x.shape[0], W.shape[0], W.shape[1]
+                dW = torch.empty(M, Nn, dtype=torch.float32, device=x.device)
+                ws = workspace(L.sgs_gemm_tn_workspace_bytes(K, M, Nn), x.device)
+                _lib.check(L.sgs_gemm_tn(_ptr(dxl), _ptr(x.contiguous(), torch.float32), K, M, Nn, _ptr(dW), ws.data_ptr(), ws.numel(),
+                                         _stream()), "sgs_gemm_tn")
+            if need_x:
+                dx = dxl @ W
+        if ctx.has_handle and ctx.needs_input_grad[2]:
+            g = torch.empty(gr.n_edges + gr.N, dtype=torch.float32, device=dY.device)
+            gw, gl = g[:gr.n_edges], g[gr.n_edges:]
+            _lib.check(L.sgs_sddmm_csr(_ptr(dZ), _ptr(xl), N, D, gr.n_edges, _ptr(gr.in_ptr), _ptr(gr.in_src), _ptr(gr.in_eid),
+                                       gw.data_ptr(), gl.data_ptr(), _stream()), "sgs_sddmm_csr")
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            dbias = _colsum(dZ)
+        return dx, dW, g, dbias, None, None, None, None, None, None
+
+
+def gcn_layer(x, W, bias, nm: Norm, act=ACT_NONE, p=0.0, seed=0, site=0, xl=None):
+    """act(A_hat (x W^T) + bias) with autograd to x, W, bias and (through nm.handle) the edge weights.
+    Returns (Y, xl) where xl = x W^T (detached) can be passed back in for another graph over the same x, W."""
+    _need_gpu(x, W, bias)
+    if x.dtype != torch.float32 or x.dim() != 2 or x.shape[0] != nm.graph.N:
+        raise RuntimeError("gcn_layer: x must be float32 [N, F]")
+    return _GCNLayer.apply(x, W, nm.handle, bias, nm, act, float(p), int(seed), int(site), xl)
