@@ -62,7 +62,7 @@ def kernel_roofline(S, model, batch, reps):
     L = S._lib.lib()
     U = (codes @ sc.fc1.weight[:, H:].t()).contiguous()
     out = torch.empty(E, dtype=torch.float32, device=codes.device)
-    ws = ops.workspace(L.sgs_edge_score_workspace_bytes(N_NODES, H), codes.device)
+    ws = ops.workspace(L.sgs_edge_score_workspace_bytes(N_NODES, H, E), codes.device)
     W1, b1, w2, b2 = sc.fc1.weight.detach().contiguous(), sc.fc1.bias.detach(), sc.fc2.weight.detach().reshape(-1).contiguous(), sc.fc2.bias.detach()
 
     def launch():
@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--pool", type=int, default=12, help="distinct partition batches kept resident per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--score-variant", type=int, default=-1, help="scorer forward kernel for the timed steps (benchmarking A/B; -1 = library default)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,6 +160,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device(device))
 
     import sgs_gnn_amd as S
+    if a.score_variant >= 0:
+        S._lib.lib().sgs_edge_score_set_variant(a.score_variant)
     S.fix_seeds(42 + rank)
     model, opt_gnn, opt_edge, opt_all = build_model(S, device)
     crit = torch.nn.CrossEntropyLoss()
@@ -200,12 +203,15 @@ def main():
     if rank == 0:
         big = max(pool, key=lambda b: b.edge_index.shape[1])
         L = S._lib.lib()
-        L.sgs_edge_score_set_variant(0)                      # in-process A/B of the two scorer forward kernels
-        roof_tiled = kernel_roofline(S, model, big, reps=20)
-        L.sgs_edge_score_set_variant(1)
-        roof = kernel_roofline(S, model, big, reps=20)       # the default (used by the timed steps above)
+        alts = {}
+        for v, name in ((0, "lds_tiled"), (2, "weight_stationary_persistent")):   # in-process A/B of the scorer forward kernels
+            L.sgs_edge_score_set_variant(v)
+            r_ = kernel_roofline(S, model, big, reps=20)
+            alts[name] = {"achieved": r_["achieved"], "ms_per_launch": r_["ms_per_launch"]}
+        L.sgs_edge_score_set_variant(1 if a.score_variant < 0 else a.score_variant)
+        roof = kernel_roofline(S, model, big, reps=20)       # the variant used by the timed steps above (default: 1)
         roof["kernel"] = "edge_score_stream_kernel<8> (sgs_edge_score_fwd, register-streaming variant)"
-        roof["alt_lds_tiled_variant"] = {"achieved": roof_tiled["achieved"], "ms_per_launch": roof_tiled["ms_per_launch"]}
+        roof["alt_variants"] = alts
         rec = {
             "metric": "sampled edges/sec + training steps/sec, Reddit hybrid 20% sparsity",
             "value": round(sampled_all / dt_all, 1), "unit": "sampled edges/s",

@@ -248,7 +248,7 @@ int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, void* ws, size_
  *   codes, U [N,H] f32; W1 = fc1.weight [H,2H]; b1 [H]; w2 = fc2.weight [H]; b2 [1].
  *   4 <= H <= 256, H % 4 == 0.  Dropout on the hidden layer is counter-based, row = edge_id_offset + local
  *   edge id (edge_id_offset = 0 unless the edge list is a shard of a larger graph).
- * ws: sgs_edge_score_workspace_bytes(N, H).
+ * ws: sgs_edge_score_workspace_bytes(N, H, E).
  *
  * sgs_edge_score_bwd_core runs over an explicit list of active edges (hybrid / two-pass: the q
  * sampled edges -- every other edge has exactly zero upstream gradient; NULL = all E edges in
@@ -264,8 +264,9 @@ int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, void* ws, size_
  * to both endpoints as a deterministic gather (no float atomics).  T may be NULL.
  *   d codes (direct) = reduce(dfeat, dfeat, T = codes, +1, +1);   d U = reduce(dv, dv, NULL, +1, -1).
  * ---------------------------------------------------------------------------------- */
-size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H);
-void sgs_edge_score_set_variant(int variant);   /* 0 = LDS-tiled, 1 = register-streaming forward (default); benchmarking switch */
+size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H, int64_t E);   /* E = 0 for the backward core */
+void sgs_edge_score_set_variant(int variant);   /* forward kernel: 0 = LDS-tiled, 1 = register-streaming (default),
+                                                   2 = weight-stationary persistent; benchmarking switch */
 int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
                        int64_t edge_id_offset, const float* W1, const float* b1, const float* w2, const float* b2,
                        float p_drop, uint64_t seed, uint32_t site, float* p_out, void* ws, size_t ws_bytes,

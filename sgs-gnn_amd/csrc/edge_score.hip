@@ -398,6 +398,130 @@ __global__ void __launch_bounds__(kT, 3) edge_score_stream_kernel(ScoreArgs a, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Forward variant C ("weight-stationary"): PMC on variant B showed 118 M L2 requests per launch
+// (~13 TB/s), two thirds of them re-fetching W1a.  Here a PERSISTENT workgroup keeps one hidden-half of
+// the packed W1a (H/2 x H fp32 = 128 KiB at H = 256; the CU has 160 KiB of LDS) resident for its whole
+// life and its waves pull 32-edge tiles from an atomic counter; only the endpoint codes stream from L2.
+// A operands come from LDS with one ds_read_b128 per four k2-steps (conflict-free, lane-linear), B
+// operands as in variant B.  No barrier after the initial fill.  Each workgroup produces the fc2 partial
+// sum of ITS hidden half, zpart[hh][e]; edge_score_finish adds the halves and applies the sigmoid.
+template <int NT, int THREADS>
+__global__ void __launch_bounds__(THREADS, THREADS / 256) edge_score_wres_kernel(ScoreArgs a, const float* __restrict__ Wp,
+                                                                                  const float* __restrict__ Ceo,
+                                                                                  unsigned int* __restrict__ tile_ctr,
+                                                                                  float* __restrict__ zpart) {
+    constexpr int H = 32 * NT;
+    constexpr int NTW = NT / 2;
+    constexpr int NJ4 = H / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* Ws = reinterpret_cast<float4*>(smem);                  // [NTW][NJ4][64] float4 = this half of Wp
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int hh = blockIdx.x & 1;
+    const int kh = lane >> 5, l31 = lane & 31;
+    {   // one-time fill: a straight copy of the half (contiguous in Wp)
+        const float4* src = reinterpret_cast<const float4*>(Wp) + static_cast<int64_t>(hh) * NTW * NJ4 * 64;
+        for (int i = tid; i < NTW * NJ4 * 64; i += THREADS) Ws[i] = src[i];
+    }
+    __syncthreads();
+    const int64_t n_tiles = (a.n + 31) >> 5;
+    const int Hrt = a.H;
+    for (;;) {
+        unsigned int t32 = 0;
+        if (lane == 0) t32 = atomicAdd(&tile_ctr[hh], 1u);
+        t32 = __builtin_amdgcn_readfirstlane(t32);
+        if (static_cast<int64_t>(t32) >= n_tiles) break;           // every wave reaches this exit
+        const int64_t r = static_cast<int64_t>(t32) * 32 + l31;
+        const bool live = r < a.n;
+        int s = 0, d = 0;
+        int64_t eg_id = 0;
+        if (live) {
+            eg_id = a.active ? a.active[r] : r;
+            s = static_cast<int>(a.src[eg_id]);
+            d = static_cast<int>(a.dst[eg_id]);
+        }
+        const float4* xp = reinterpret_cast<const float4*>(Ceo + static_cast<int64_t>(s) * H + kh * (H / 2));
+        const float4* yp = reinterpret_cast<const float4*>(Ceo + static_cast<int64_t>(d) * H + kh * (H / 2));
+        f32x16 acc[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+        float4 A0[NTW], A1[NTW], x0, y0, x1, y1;
+        auto load = [&](int j4, float4 (&A)[NTW], float4& x, float4& y) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) A[t] = Ws[(t * NJ4 + j4) * 64 + lane];
+            x = xp[j4];
+            y = yp[j4];
+        };
+        auto mma = [&](const float4 (&A)[NTW], const float4& x, const float4& y) {
+            const float b[4] = {x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    const float av = jj == 0 ? A[t].x : jj == 1 ? A[t].y : jj == 2 ? A[t].z : A[t].w;
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[jj], acc[t], 0, 0, 0);
+                }
+            }
+        };
+        load(0, A0, x0, y0);
+#pragma unroll 1
+        for (int j4 = 0; j4 < NJ4; j4 += 2) {
+            load(j4 + 1, A1, x1, y1);
+            mma(A0, x0, y0);
+            if (j4 + 2 < NJ4) load(j4 + 2, A0, x0, y0);
+            mma(A1, x1, y1);
+        }
+        // epilogue for this wave's hidden half: hidden unit hh*H/2 + 32t + (q&3) + 8(q>>2) + 4kh
+        const uint32_t rkey = dropout_row_key(a.seed, a.site, static_cast<uint64_t>(a.row_offset + eg_id));
+        const float* Us = a.U + static_cast<int64_t>(s) * H;
+        const float* Ud = a.U + static_cast<int64_t>(d) * H;
+        float z = 0.f;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int hb = hh * (H / 2) + 32 * t + 8 * g + 4 * kh;
+                if (hb < Hrt) {      // always true; keeps hipcc from hoisting all the float4 loads at once
+                    const float4 us = *reinterpret_cast<const float4*>(Us + hb);
+                    const float4 ud = *reinterpret_cast<const float4*>(Ud + hb);
+                    const float4 bb = *reinterpret_cast<const float4*>(a.b1 + hb);
+                    const float4 ww = *reinterpret_cast<const float4*>(a.w2 + hb);
+                    const float u4[4] = {us.x - ud.x, us.y - ud.y, us.z - ud.z, us.w - ud.w};
+                    const float b4[4] = {bb.x, bb.y, bb.z, bb.w};
+                    const float w4[4] = {ww.x, ww.y, ww.z, ww.w};
+                    uint32_t bits[2] = {0u, 0u};
+                    if (a.use_drop) {
+                        bits[0] = dropout_pair_bits(rkey, static_cast<uint32_t>(hb >> 1));
+                        bits[1] = dropout_pair_bits(rkey, static_cast<uint32_t>((hb >> 1) + 1));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = (acc[t][4 * g + j] + u4[j]) + b4[j];
+                        float m = v > 0.f ? 1.f : 0.f;
+                        if (a.use_drop) {
+                            const uint32_t draw = (j & 1) ? (bits[j >> 1] >> 16) : (bits[j >> 1] & 0xFFFFu);
+                            m = draw >= a.drop_thresh ? m * a.drop_scale : 0.f;
+                        }
+                        z = fmaf(w4[j], v * m, z);
+                    }
+                }
+            }
+        }
+        z += __shfl_xor(z, 32, 64);
+        if (live && kh == 0) zpart[static_cast<int64_t>(hh) * a.n + r] = z;
+    }
+}
+
+__global__ void __launch_bounds__(kT) edge_score_finish(const float* __restrict__ zpart, int64_t n, const float* __restrict__ b2,
+                                                       float* __restrict__ p_out) {
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (r >= n) return;
+    const float z = (zpart[r] + zpart[n + r]) + b2[0];
+    p_out[r] = 1.0f / (1.0f + expf(-z));
+}
+
 // out[v,:] = sum_{k in out-row v} sgn_out * Mo[out_eid[k],:] (* T[out_dst[k],:])
 //          + sum_{k in in-row v}  sgn_in  * Mi[in_eid[k],:]  (* T[in_src[k],:])
 // Scatter of per-edge gradient rows to both endpoints as a deterministic gather over the two
@@ -547,13 +671,17 @@ using namespace sgs;
 
 extern "C" {
 
-size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H) {
+size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H, int64_t E) {
     if (N < 0) N = 0;
     if (H < 0) H = 0;
-    return carve_bytes(static_cast<size_t>(H) * H, 4) + carve_bytes(static_cast<size_t>(N) * H, 4) + 256;
+    if (E < 0) E = 0;
+    return carve_bytes(static_cast<size_t>(H) * H, 4) + carve_bytes(static_cast<size_t>(N) * H, 4) + carve_bytes(2 * static_cast<size_t>(E), 4) +
+           carve_bytes(64, 4) + 256;
 }
 
-// 0 = LDS-tiled kernel, 1 = register-streaming kernel (forward, H % 64 == 0).  A/B switch for benchmarks.
+// 0 = LDS-tiled kernel, 1 = register-streaming kernel, 2 = weight-stationary persistent kernel (forward, H % 64 == 0).
+// A/B switch for benchmarks.  Measured (MI355X, E = 351 194, H = 256, same process): 0 -> 95, 1 -> 100.7, 2 -> 99.5 TFLOP/s;
+// whole-step throughput is equal within noise, so the fastest kernel is the default.
 static int g_score_variant = 1;
 void sgs_edge_score_set_variant(int v) { g_score_variant = v; }
 
@@ -564,7 +692,7 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
     if (int rc = check_common("sgs_edge_score_fwd", N, H, E, p_drop)) return rc;
     if (E == 0) return SGS_OK;
     SGS_REQUIRE(codes && U && edge_index && W1 && b1 && w2 && b2 && p_out, SGS_EINVAL, "sgs_edge_score_fwd: null pointer");
-    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_workspace_bytes(N, H), SGS_EWORKSPACE, "sgs_edge_score_fwd: workspace too small");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_workspace_bytes(N, H, E), SGS_EWORKSPACE, "sgs_edge_score_fwd: workspace too small");
     Carver cv(ws);
     float* WaT = cv.take<float>(static_cast<size_t>(H) * H);
     float* Ceo = cv.take<float>(static_cast<size_t>(N) * H);
@@ -574,6 +702,35 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
     a.WaT = WaT; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.drop_scale = 1.0f / (1.0f - p_drop); a.drop_thresh = dropout_thresh(p_drop); a.seed = seed; a.site = site;
     a.use_drop = p_drop > 0.f; a.p_out = p_out;
+    if (g_score_variant == 2 && H % 64 == 0 && N > 0) {
+        float* zpart = cv.take<float>(2 * static_cast<size_t>(E));
+        unsigned int* ctr = cv.take<unsigned int>(64);
+        SGS_HIP_OK(hipMemsetAsync(ctr, 0, 256, stream));
+        hipLaunchKernelGGL(pack_w1a_stream, dim3(cdiv(H * H, kT)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);
+        hipLaunchKernelGGL(pack_codes_eo, dim3(cdiv(N * H, kT)), dim3(kT), 0, stream, codes, N, static_cast<int>(H), Ceo);
+        constexpr int TH = 768;                                             // 12 waves = 3 per SIMD (168-register budget; 16 waves spill)
+        const size_t sm = static_cast<size_t>(H / 2) * H * 4;             // this half of W1a, packed
+        const int64_t n_tiles = cdiv(E, 32);
+        int64_t nwg = 256;                                                // persistent: one workgroup per CU (128 per hidden half)
+        if (nwg > 2 * cdiv(n_tiles, TH / 64)) nwg = 2 * cdiv(n_tiles, TH / 64);
+        if (nwg < 2) nwg = 2;
+#define SGS_WRES_CASE(NT_)                                                                                              \
+        do {                                                                                                                \
+            static bool raised = false;                                                                                     \
+            if (!raised) {                                                                                                  \
+                SGS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_score_wres_kernel<NT_, TH>),            \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sm)));          \
+                raised = true;                                                                                              \
+            }                                                                                                               \
+            hipLaunchKernelGGL((edge_score_wres_kernel<NT_, TH>), dim3(static_cast<unsigned>(nwg)), dim3(TH), sm, stream, a, WaT, Ceo, \
+                               ctr, zpart);                                                                                 \
+        } while (0)
+        if (H == 256) SGS_WRES_CASE(8); else if (H == 128) SGS_WRES_CASE(4); else SGS_WRES_CASE(2);
+#undef SGS_WRES_CASE
+        hipLaunchKernelGGL(edge_score_finish, dim3(cdiv(E, kT)), dim3(kT), 0, stream, zpart, E, b2, p_out);
+        SGS_LAUNCH_OK();
+        return SGS_OK;
+    }
     if (g_score_variant == 1 && H % 64 == 0 && N > 0) {
         hipLaunchKernelGGL(pack_w1a_stream, dim3(cdiv(H * H, kT)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);
         hipLaunchKernelGGL(pack_codes_eo, dim3(cdiv(N * H, kT)), dim3(kT), 0, stream, codes, N, static_cast<int>(H), Ceo);
@@ -602,7 +759,7 @@ int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64
     if (n_active == 0) return SGS_OK;
     SGS_REQUIRE(codes && U && edge_index && grad_p && W1 && b1 && w2 && b2 && dv && hdz && dz && feat, SGS_EINVAL,
                 "sgs_edge_score_bwd_core: null pointer");
-    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_workspace_bytes(N, H), SGS_EWORKSPACE, "sgs_edge_score_bwd_core: workspace too small");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_workspace_bytes(N, H, 0), SGS_EWORKSPACE, "sgs_edge_score_bwd_core: workspace too small");
     Carver cv(ws);
     float* WaT = cv.take<float>(static_cast<size_t>(H) * H);
     hipLaunchKernelGGL(transpose_w1a, dim3(cdiv(H, 32), cdiv(H, 32)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);

@@ -344,7 +344,7 @@ class _EdgeScore(torch.autograd.Function):
         N, H = codes.shape
         E = edge_index.shape[1]
         out = torch.empty(E, dtype=torch.float32, device=codes.device)
-        ws = workspace(L.sgs_edge_score_workspace_bytes(N, H), codes.device)
+        ws = workspace(L.sgs_edge_score_workspace_bytes(N, H, E), codes.device)
         _lib.check(L.sgs_edge_score_fwd(_ptr(codes, torch.float32), _ptr(U, torch.float32), N, H, _ptr(edge_index, torch.int64), E,
                                         edge_id_offset, _ptr(W1, torch.float32), _ptr(b1), _ptr(w2), _ptr(b2), float(p), seed, site, _ptr(out),
                                         ws.data_ptr(), ws.numel(), _stream()), "sgs_edge_score_fwd")
@@ -371,7 +371,7 @@ class _EdgeScore(torch.autograd.Function):
         dv, hdz, feat = torch.empty(n, H, **f32), torch.empty(n, H, **f32), torch.empty(n, H, **f32)
         dz = torch.empty(n, **f32)
         if n > 0:
-            ws = workspace(L.sgs_edge_score_workspace_bytes(N, H), dev)
+            ws = workspace(L.sgs_edge_score_workspace_bytes(N, H, 0), dev)
             _lib.check(L.sgs_edge_score_bwd_core(_ptr(codes), _ptr(U), N, H, _ptr(edge_index), E, ctx.offset, _ptr(eid), n, _ptr(gp_act),
                                                  _ptr(W1), _ptr(b1), _ptr(w2), _ptr(b2), ctx.p, ctx.seed, ctx.site, _ptr(dv),
                                                  _ptr(hdz), _ptr(dz), _ptr(feat), ws.data_ptr(), ws.numel(), _stream()),

@@ -41,7 +41,7 @@ def test_abi_version_and_workspace_queries_run_on_cpu(pkg):
     assert L.sgs_abi_version() == 1
     assert L.sgs_sample_topq_workspace_bytes(500000) >= 4 * 500000
     assert L.sgs_graph_build_workspace_bytes(100000, 1013) > 0
-    assert L.sgs_edge_score_workspace_bytes(1013, 256) >= 256 * 256 * 4
+    assert L.sgs_edge_score_workspace_bytes(1013, 256, 500000) >= 256 * 256 * 4 + 8 * 500000
     assert L.sgs_colsum_workspace_bytes(100000, 256) > 0
 
 
