@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--pool", type=int, default=12, help="distinct partition batches kept resident per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--score-variant", type=int, default=-1, help="scorer forward kernel for the timed steps (benchmarking A/B; -1 = library default)")
+    ap.add_argument("--hipgraph", type=int, default=0, help="1: replay each partition's step from captured HIP graphs (stepgraph.py); "
+                    "every pool partition is visited twice (eager, capture) before the W warm-up steps")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -170,6 +172,9 @@ def main():
     # partition pool (per rank: its own shard of the stream), resident in HBM before timing
     pool = S.reddit_partition_stream(num_parts=a.pool, seed=1000 + rank, nfeat=NFEAT, ncls=NCLS, n=N_NODES, q=Q, device=device)
     warm = [pool[i % len(pool)] for i in range(a.warmup)]
+    if a.hipgraph and world == 1:
+        args.sgs_hipgraph = True
+        warm = list(pool) * 2 + warm
     timed = [pool[i % len(pool)] for i in range(a.steps)]
     sampled = sum(Q for b in timed if b.edge_index.shape[1] > Q)
 
@@ -221,7 +226,8 @@ def main():
             "config": {"workload": "Reddit-like METIS partition stream (S3): n=1013 F=602 C=41 H=256, E_b in [60k,500k] "
                                    "(52% above q), q=100000, hybrid pipeline, EdgeProbGCN scorer, conditional gate, reg1+reg2, "
                                    "dropout 0.3, Adam x2", "pool": a.pool, "partitions_above_q": sum(1 for b in timed if b.edge_index.shape[1] > Q),
-                       "parallelism": f"dp{world} (partition-sharded, 1 flat gradient all-reduce/step)" if world > 1 else "single"},
+                       "parallelism": f"dp{world} (partition-sharded, 1 flat gradient all-reduce/step)" if world > 1 else "single",
+                       "hipgraph_replay": bool(getattr(args, "sgs_hipgraph", False))},
             "mean_loss": round(ret[0], 5), "conditional_updates": ret[2], "total_updates": ret[3],
             "roofline": roof,
         }

@@ -51,6 +51,11 @@ const char* sgs_last_error(void);
  *                     same bits the fused kernels apply (reference: nn.Dropout at
  *                     model.py:107,121,160).  Only tests need the materialised form.
  * ---------------------------------------------------------------------------------- */
+/* HIP-graph replay support: seeds are passed by value and therefore frozen in a captured graph.  When a
+ * device word is registered here, every RNG-consuming kernel uses seed + 0x9E3779B97F4A7C15 * (*epoch_dev);
+ * a captured increment of that word makes every replay draw fresh noise and dropout masks.  NULL (the
+ * default) = seeds used exactly as given.  Process-wide; the word must outlive all launches that read it. */
+int sgs_rng_set_epoch_buffer(const uint64_t* epoch_dev);
 int sgs_exp_noise(uint64_t seed, uint64_t stream_id, int64_t E, float* noise, sgs_stream_t stream);
 int sgs_dropout_keep(uint64_t seed, uint32_t site, int64_t rows, int64_t cols, float p, uint8_t* keep,
                      sgs_stream_t stream);

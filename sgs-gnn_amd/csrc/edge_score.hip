@@ -58,6 +58,7 @@ struct ScoreArgs {
     float drop_scale;
     uint32_t drop_thresh;
     uint64_t seed;
+    const uint64_t* epoch;   // RNG epoch word (HIP-graph replay) or nullptr
     uint32_t site;
     int use_drop;
     float* p_out;            // forward: [n]
@@ -193,7 +194,7 @@ __global__ void __launch_bounds__(kT, 3) edge_score_kernel(ScoreArgs a) {
     const int64_t r = row0 + el;
     const bool live = r < a.n;
     const int64_t eg_id = live ? (a.active ? a.active[r] : r) : 0;   // global edge id: dropout row
-    const uint32_t rkey = dropout_row_key(a.seed, a.site, static_cast<uint64_t>(a.row_offset + eg_id));
+    const uint32_t rkey = dropout_row_key(fold_epoch(a.seed, a.epoch), a.site, static_cast<uint64_t>(a.row_offset + eg_id));
     const float* Us = a.U + static_cast<int64_t>(s_idx[el]) * H;
     const float* Ud = a.U + static_cast<int64_t>(d_idx[el]) * H;
     float z = 0.f;
@@ -354,7 +355,7 @@ __global__ void __launch_bounds__(kT, 3) edge_score_stream_kernel(ScoreArgs a, c
 
     // ---- epilogue (same as the tiled kernel): hidden unit hh*H/2 + 32t + (q&3) + 8(q>>2) + 4kh
     const int Hrt = a.H;
-    const uint32_t rkey = dropout_row_key(a.seed, a.site, static_cast<uint64_t>(a.row_offset + eg_id));
+    const uint32_t rkey = dropout_row_key(fold_epoch(a.seed, a.epoch), a.site, static_cast<uint64_t>(a.row_offset + eg_id));
     const float* Us = a.U + static_cast<int64_t>(s) * H;
     const float* Ud = a.U + static_cast<int64_t>(d) * H;
     float z = 0.f;
@@ -474,7 +475,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256) edge_score_wres_kernel
             mma(A1, x1, y1);
         }
         // epilogue for this wave's hidden half: hidden unit hh*H/2 + 32t + (q&3) + 8(q>>2) + 4kh
-        const uint32_t rkey = dropout_row_key(a.seed, a.site, static_cast<uint64_t>(a.row_offset + eg_id));
+        const uint32_t rkey = dropout_row_key(fold_epoch(a.seed, a.epoch), a.site, static_cast<uint64_t>(a.row_offset + eg_id));
         const float* Us = a.U + static_cast<int64_t>(s) * H;
         const float* Ud = a.U + static_cast<int64_t>(d) * H;
         float z = 0.f;
@@ -700,7 +701,7 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
     a.codes = codes; a.U = U; a.src = edge_index; a.dst = edge_index + E; a.active = nullptr; a.n = E; a.H = static_cast<int>(H);
     a.row_offset = edge_id_offset;
     a.WaT = WaT; a.b1 = b1; a.w2 = w2; a.b2 = b2;
-    a.drop_scale = 1.0f / (1.0f - p_drop); a.drop_thresh = dropout_thresh(p_drop); a.seed = seed; a.site = site;
+    a.drop_scale = 1.0f / (1.0f - p_drop); a.drop_thresh = dropout_thresh(p_drop); a.seed = seed; a.epoch = epoch_ptr(); a.site = site;
     a.use_drop = p_drop > 0.f; a.p_out = p_out;
     if (g_score_variant == 2 && H % 64 == 0 && N > 0) {
         float* zpart = cv.take<float>(2 * static_cast<size_t>(E));
@@ -767,7 +768,7 @@ int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64
     a.codes = codes; a.U = U; a.src = edge_index; a.dst = edge_index + E; a.active = active_eid; a.n = n_active;
     a.row_offset = edge_id_offset;
     a.H = static_cast<int>(H); a.WaT = WaT; a.b1 = b1; a.w2 = w2; a.b2 = b2;
-    a.drop_scale = 1.0f / (1.0f - p_drop); a.drop_thresh = dropout_thresh(p_drop); a.seed = seed; a.site = site;
+    a.drop_scale = 1.0f / (1.0f - p_drop); a.drop_thresh = dropout_thresh(p_drop); a.seed = seed; a.epoch = epoch_ptr(); a.site = site;
     a.use_drop = p_drop > 0.f; a.gp = grad_p; a.dv = dv; a.hdz = hdz; a.dz = dz; a.feat = feat;
     return launch_score<true>(a, stream);
 }

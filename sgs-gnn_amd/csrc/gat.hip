@@ -25,8 +25,10 @@ __global__ void __launch_bounds__(kT) gat_alpha_fwd(const float* __restrict__ a_
                                                    const int* __restrict__ in_ptr, const int* __restrict__ in_src,
                                                    const int* __restrict__ in_eid, float slope, float drop_scale,
                                                    uint32_t drop_thresh, int use_drop, uint64_t seed, uint32_t site,
-                                                   float* __restrict__ soft_in, float* __restrict__ soft_loop,
-                                                   float* __restrict__ alpha_in, float* __restrict__ alpha_loop) {
+                                                   const uint64_t* __restrict__ epoch, float* __restrict__ soft_in,
+                                                   float* __restrict__ soft_loop, float* __restrict__ alpha_in,
+                                                   float* __restrict__ alpha_loop) {
+    seed = fold_epoch(seed, epoch);
     const int lane = threadIdx.x & 63;
     const int64_t i = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
     if (i >= N) return;
@@ -77,9 +79,11 @@ __global__ void __launch_bounds__(kT) gat_alpha_bwd(const float* __restrict__ a_
                                                    const int* __restrict__ in_ptr, const int* __restrict__ in_src,
                                                    const int* __restrict__ in_eid, float slope, float drop_scale,
                                                    uint32_t drop_thresh, int use_drop, uint64_t seed, uint32_t site,
+                                                   const uint64_t* __restrict__ epoch,
                                                    const float* __restrict__ soft_in, const float* __restrict__ soft_loop,
                                                    const float* __restrict__ galpha, const float* __restrict__ gloop,
                                                    float* __restrict__ ge, float* __restrict__ gsl, float* __restrict__ d_ad) {
+    seed = fold_epoch(seed, epoch);
     const int lane = threadIdx.x & 63;
     const int64_t i = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
     if (i >= N) return;
@@ -145,7 +149,7 @@ int sgs_gat_alpha_fwd(const float* a_src, const float* a_dst, int64_t N, int64_t
     SGS_REQUIRE(a_src && a_dst && in_ptr && soft_loop && alpha_loop && (n_edges == 0 || (in_src && in_eid && soft_in && alpha_in)),
                 SGS_EINVAL, "sgs_gat_alpha_fwd: null pointer");
     hipLaunchKernelGGL(gat_alpha_fwd, dim3(cdiv(N * 64, kT)), dim3(kT), 0, stream, a_src, a_dst, N, in_ptr, in_src, in_eid,
-                       negative_slope, 1.0f / (1.0f - p_drop), dropout_thresh(p_drop), p_drop > 0.f ? 1 : 0, seed, site, soft_in,
+                       negative_slope, 1.0f / (1.0f - p_drop), dropout_thresh(p_drop), p_drop > 0.f ? 1 : 0, seed, site, epoch_ptr(), soft_in,
                        soft_loop, alpha_in, alpha_loop);
     SGS_LAUNCH_OK();
     return SGS_OK;
@@ -160,7 +164,7 @@ int sgs_gat_alpha_bwd(const float* a_src, const float* a_dst, int64_t N, int64_t
     if (N == 0) return SGS_OK;
     SGS_REQUIRE(a_src && a_dst && in_ptr && soft_loop && gloop && g_selfloop && d_a_dst, SGS_EINVAL, "sgs_gat_alpha_bwd: null pointer");
     hipLaunchKernelGGL(gat_alpha_bwd, dim3(cdiv(N * 64, kT)), dim3(kT), 0, stream, a_src, a_dst, N, in_ptr, in_src, in_eid,
-                       negative_slope, 1.0f / (1.0f - p_drop), dropout_thresh(p_drop), p_drop > 0.f ? 1 : 0, seed, site, soft_in,
+                       negative_slope, 1.0f / (1.0f - p_drop), dropout_thresh(p_drop), p_drop > 0.f ? 1 : 0, seed, site, epoch_ptr(), soft_in,
                        soft_loop, galpha, gloop, g_edge, g_selfloop, d_a_dst);
     SGS_LAUNCH_OK();
     return SGS_OK;

@@ -262,7 +262,8 @@ __global__ void __launch_bounds__(kT) dis_from_degree(const float* __restrict__ 
 // Y = act(X + bias) with the same fused ReLU / counter-based dropout as the SpMM epilogue.
 __global__ void __launch_bounds__(kT) bias_act(const float* __restrict__ X, const float* __restrict__ bias, int64_t N, int64_t D, int act,
                                               float drop_scale, uint32_t drop_thresh, uint64_t seed, uint32_t site,
-                                              float* __restrict__ Y) {
+                                              const uint64_t* __restrict__ epoch, float* __restrict__ Y) {
+    seed = fold_epoch(seed, epoch);
     const int64_t idx = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
     if (idx >= N * D) return;
     const int64_t i = idx / D;
@@ -400,9 +401,10 @@ __global__ void __launch_bounds__(kT) spmm_csr(const float* __restrict__ X, int6
                                               const int* __restrict__ col, const float* __restrict__ val,
                                               const float* __restrict__ diag, const float* __restrict__ bias, int act,
                                               float drop_scale, uint32_t drop_thresh, uint64_t seed, uint32_t site,
-                                              float* __restrict__ Y) {
+                                              const uint64_t* __restrict__ epoch, float* __restrict__ Y) {
     using V = typename VecT<VEC>::type;
     constexpr int RPB = kT / LPR;   // rows per block
+    seed = fold_epoch(seed, epoch);
     const int sub = threadIdx.x % LPR;
     const int64_t i = static_cast<int64_t>(blockIdx.x) * RPB + threadIdx.x / LPR;
     if (i >= N) return;
@@ -454,9 +456,10 @@ __global__ void __launch_bounds__(kT) spmm_csr_rowblock(const float* __restrict_
                                                        const int* __restrict__ col, const float* __restrict__ val,
                                                        const float* __restrict__ diag, const float* __restrict__ bias, int act,
                                                        float drop_scale, uint32_t drop_thresh, uint64_t seed, uint32_t site,
-                                                       float* __restrict__ Y) {
+                                                       const uint64_t* __restrict__ epoch, float* __restrict__ Y) {
     using V = typename VecT<VEC>::type;
     __shared__ float part[4][64 * VEC];
+    seed = fold_epoch(seed, epoch);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t i = blockIdx.x;
     const int b = ptr[i], e = ptr[i + 1];
@@ -772,7 +775,7 @@ int sgs_bias_act(const float* X, const float* bias, int64_t N, int64_t D, int ac
     SGS_REQUIRE(X && Y, SGS_EINVAL, "sgs_bias_act: null pointer");
     if (act == SGS_ACT_RELU_DROPOUT && p_drop == 0.f) act = SGS_ACT_RELU;
     hipLaunchKernelGGL(bias_act, dim3(cdiv(N * D, kT)), dim3(kT), 0, stream, X, bias, N, D, act, 1.0f / (1.0f - p_drop),
-                       dropout_thresh(p_drop), seed, site, Y);
+                       dropout_thresh(p_drop), seed, site, epoch_ptr(), Y);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }
@@ -867,12 +870,12 @@ int sgs_spmm_csr(const float* X, int64_t N, int64_t D, int64_t nnz, const int32_
     if (N <= 65536 && nnz >= 16 * N) {        // few, long rows: a workgroup per row
         if (vec == 4)
             hipLaunchKernelGGL((spmm_csr_rowblock<4>), dim3(static_cast<unsigned>(N)), dim3(kT), 0, stream, X, N, D, ptr, col, val,
-                               diag, bias, act, scale, th, seed, site, Y);
+                               diag, bias, act, scale, th, seed, site, epoch_ptr(), Y);
         else
             hipLaunchKernelGGL((spmm_csr_rowblock<1>), dim3(static_cast<unsigned>(N)), dim3(kT), 0, stream, X, N, D, ptr, col, val,
-                               diag, bias, act, scale, th, seed, site, Y);
+                               diag, bias, act, scale, th, seed, site, epoch_ptr(), Y);
     } else {
-        DISPATCH_VEC_LPR(spmm_csr, vec, lpr, N, X, N, D, ptr, col, val, diag, bias, act, scale, th, seed, site, Y);
+        DISPATCH_VEC_LPR(spmm_csr, vec, lpr, N, X, N, D, ptr, col, val, diag, bias, act, scale, th, seed, site, epoch_ptr(), Y);
     }
     SGS_LAUNCH_OK();
     return SGS_OK;

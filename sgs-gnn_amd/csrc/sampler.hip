@@ -97,12 +97,13 @@ __device__ __forceinline__ float sample_prob(float pv, float Zeps, float mx, flo
 template <int MODE>
 __global__ void __launch_bounds__(kThreads) keys_hist0(const float* __restrict__ p, const float* __restrict__ prior,
                                                       const float* __restrict__ noise, uint64_t seed,
-                                                      uint64_t stream_id, int64_t edge_offset, int64_t E, float one_minus_c, float c,
+                                                      uint64_t stream_id, const uint64_t* __restrict__ epoch, int64_t edge_offset, int64_t E, float one_minus_c, float c,
                                                       const float* __restrict__ scal, uint32_t* __restrict__ keys,
                                                       float* __restrict__ keys_out, uint32_t* __restrict__ hist) {
     __shared__ uint32_t lh[kBins];
     for (int i = threadIdx.x; i < kBins; i += kThreads) lh[i] = 0;
     __syncthreads();
+    seed = fold_epoch(seed, epoch);
     const float Z = scal[0];
     const float Zeps = (MODE == SGS_SAMPLE_LEARNED) ? __fadd_rn(Z, 1e-12f) : Z;
     const float mx = (MODE == SGS_SAMPLE_PRIOR) ? scal[1] : 0.f;
@@ -362,13 +363,15 @@ __global__ void select_all(int64_t E, const float* __restrict__ p, const int64_t
     }
 }
 
-__global__ void exp_noise_kernel(uint64_t seed, uint64_t stream_id, int64_t E, float* __restrict__ noise) {
+__global__ void exp_noise_kernel(uint64_t seed, uint64_t stream_id, const uint64_t* __restrict__ epoch, int64_t E, float* __restrict__ noise) {
+    seed = fold_epoch(seed, epoch);
     const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (e < E) noise[e] = exp_noise_at(seed, stream_id, static_cast<uint64_t>(e));
 }
 
-__global__ void dropout_keep_kernel(uint64_t seed, uint32_t site, int64_t rows, int64_t cols, uint32_t thresh,
-                                    uint8_t* __restrict__ keep) {
+__global__ void dropout_keep_kernel(uint64_t seed, uint32_t site, const uint64_t* __restrict__ epoch, int64_t rows, int64_t cols,
+                                    uint32_t thresh, uint8_t* __restrict__ keep) {
+    seed = fold_epoch(seed, epoch);
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < rows * cols) {
         const int64_t r = i / cols;
@@ -467,7 +470,7 @@ int sgs_exp_noise(uint64_t seed, uint64_t stream_id, int64_t E, float* noise, sg
     SGS_REQUIRE(E >= 0 && (E == 0 || noise), SGS_EINVAL, "sgs_exp_noise: bad arguments");
     if (E == 0) return SGS_OK;
     hipLaunchKernelGGL(exp_noise_kernel, dim3(cdiv(E, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), seed,
-                       stream_id, E, noise);
+                       stream_id, epoch_ptr(), E, noise);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }
@@ -479,7 +482,7 @@ int sgs_dropout_keep(uint64_t seed, uint32_t site, int64_t rows, int64_t cols, f
     if (rows * cols == 0) return SGS_OK;
     SGS_REQUIRE(keep, SGS_EINVAL, "sgs_dropout_keep: null output");
     hipLaunchKernelGGL(dropout_keep_kernel, dim3(cdiv(rows * cols, 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), seed, site, rows, cols, dropout_thresh(p), keep);
+                       static_cast<hipStream_t>(stream), seed, site, epoch_ptr(), rows, cols, dropout_thresh(p), keep);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }
@@ -548,10 +551,10 @@ int sgs_sample_topq(int mode, const float* p, const float* prior, double degree_
     const float one_minus_c = static_cast<float>(1.0 - degree_bias_coef);
     const float c = static_cast<float>(degree_bias_coef);
     if (mode == SGS_SAMPLE_LEARNED)
-        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_LEARNED>, grid, blk, 0, stream, p, prior, noise, seed, stream_id, int64_t(0), E,
+        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_LEARNED>, grid, blk, 0, stream, p, prior, noise, seed, stream_id, epoch_ptr(), int64_t(0), E,
                            one_minus_c, c, scal, keys, keys_out, hist);
     else
-        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_PRIOR>, grid, blk, 0, stream, p, nullptr, noise, seed, stream_id, int64_t(0), E,
+        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_PRIOR>, grid, blk, 0, stream, p, nullptr, noise, seed, stream_id, epoch_ptr(), int64_t(0), E,
                            one_minus_c, c, scal, keys, keys_out, hist);
     hipLaunchKernelGGL(select_digit, dim3(1), blk, 0, stream, hist, kShift0, 1, static_cast<uint32_t>(q), st);
     hipLaunchKernelGGL(hist_next, grid, blk, 0, stream, keys, E, kShift1, kMask1, kShift0, st, hist);
@@ -615,10 +618,10 @@ int sgs_sampler_shard_keys(int mode, const float* p, const float* prior, double 
     const float one_minus_c = static_cast<float>(1.0 - degree_bias_coef), c = static_cast<float>(degree_bias_coef);
     const dim3 grid(static_cast<unsigned>(cdiv(E, kChunk))), blk(kThreads);
     if (mode == SGS_SAMPLE_LEARNED)
-        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_LEARNED>, grid, blk, 0, stream, p, prior, noise, seed, stream_id, edge_offset, E,
+        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_LEARNED>, grid, blk, 0, stream, p, prior, noise, seed, stream_id, epoch_ptr(), edge_offset, E,
                            one_minus_c, c, scal, keys, keys_out, hist);
     else
-        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_PRIOR>, grid, blk, 0, stream, p, nullptr, noise, seed, stream_id, edge_offset, E,
+        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_PRIOR>, grid, blk, 0, stream, p, nullptr, noise, seed, stream_id, epoch_ptr(), edge_offset, E,
                            one_minus_c, c, scal, keys, keys_out, hist);
     SGS_LAUNCH_OK();
     return SGS_OK;

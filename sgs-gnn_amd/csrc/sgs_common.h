@@ -40,6 +40,15 @@ void set_error(const char* fmt, ...);
         }                                                                                 \
     } while (0)
 
+// ---------------------------------------------------------------- RNG epoch (HIP-graph replay)
+// Seeds are kernel arguments by value, which a captured graph freezes.  When the host registers a device word
+// (sgs_rng_set_epoch_buffer), every RNG-consuming kernel folds *epoch into its seed, so a captured `epoch += 1`
+// makes each replay draw fresh noise / dropout masks.  nullptr (default) = seeds used as given.
+const uint64_t* epoch_ptr();
+__device__ __forceinline__ uint64_t fold_epoch(uint64_t seed, const uint64_t* __restrict__ epoch) {
+    return epoch ? seed + 0x9E3779B97F4A7C15ULL * (*epoch) : seed;
+}
+
 // ---------------------------------------------------------------- workspace carving (256-B aligned)
 struct Carver {
     char* base;

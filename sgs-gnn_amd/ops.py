@@ -12,6 +12,8 @@ SAMPLE_LEARNED, SAMPLE_PRIOR = 0, 1
 ACT_NONE, ACT_RELU, ACT_RELU_DROPOUT = 0, 1, 2
 
 _workspaces = {}
+_retired_workspaces = []      # arenas outgrown while HIP graphs may still reference them (pin_workspaces)
+_pin_workspaces = False
 
 
 def _need_gpu(*tensors):
@@ -49,12 +51,36 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     key = (device.index if device.index is not None else torch.cuda.current_device())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
+        if ws is not None and _pin_workspaces:
+            _retired_workspaces.append(ws)
         ws = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
 
 
+def pin_workspaces(on: bool = True) -> None:
+    """Once captured HIP graphs hold the arena's address, an outgrown arena must stay allocated."""
+    global _pin_workspaces
+    _pin_workspaces = _pin_workspaces or bool(on)
+
+
 # ------------------------------------------------------------------ randomness
+_rng_epoch = None       # keeps the registered device word alive
+
+
+def set_rng_epoch_buffer(epoch) -> None:
+    """Register (or clear with None) the device word every RNG-consuming kernel folds into its seed
+    (sgs_rng_set_epoch_buffer): a HIP graph that increments it draws fresh noise on every replay."""
+    global _rng_epoch
+    L = _lib.lib()
+    if epoch is not None:
+        _need_gpu(epoch)
+        if epoch.dtype != torch.int64 or epoch.numel() != 1:
+            raise RuntimeError("sgs_gnn_amd: the RNG epoch buffer is one int64 device word")
+    _lib.check(L.sgs_rng_set_epoch_buffer(None if epoch is None else epoch.data_ptr()), "sgs_rng_set_epoch_buffer")
+    _rng_epoch = epoch
+
+
 def exp_noise(seed: int, stream_id: int, E: int, device) -> torch.Tensor:
     L = _lib.lib()
     out = torch.empty(E, dtype=torch.float32, device=device)

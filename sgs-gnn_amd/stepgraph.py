@@ -1,0 +1,207 @@
+"""Opt-in HIP-graph replay of the per-partition training step (`args.sgs_hipgraph = True`).
+
+Why: at partition scale (n ~ 1e3 nodes, E <= 5e5 edges) one hybrid step is ~120 kernel launches of a few
+microseconds each, and the Python + launch time per step exceeds the GPU-busy time.
+The C ABI never allocates or synchronises, so a step's device work is capturable as is.  Per partition
+(keyed on the batch's tensors) the step is recorded once into HIP graphs and replayed afterwards:
+
+    E_b >  q :  G1 = epoch += 1; prior draw -> scores -> learned draw -> CSR build -> learned / random encoders ->
+                     the two correct-counts                          (training.sampled_forward)
+                host reads the 16-byte gate buffer (the step's one read-back, as in eager mode)
+                G2L = CE + reg1 + reg2 and backward of the learned branch   |   G2R = CE and backward of the random branch
+    E_b <= q :  G  = epoch += 1; encoder on all edges, CE, backward
+
+The optimiser steps stay eager (they belong to the caller); after a replay `.grad` of every parameter is
+pointed at that graph's static gradient buffer (or None when the branch gives it no gradient - Adam must
+skip those, as in eager mode).
+
+Randomness: seeds are launch arguments and therefore frozen at capture; every capture starts by
+incrementing the registered RNG epoch word (ops.set_rng_epoch_buffer) which all RNG-consuming kernels fold
+into their seed, so each replay draws fresh Exp(1) noise and dropout masks.  The random stream therefore
+differs from eager mode's (same distributions); parity tests run eager mode.
+
+First visit of a partition runs eagerly (warm-up: lazy library initialisation, CSR cache, workspace growth),
+the second visit captures (and replays), later visits only replay.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+import os
+_DEBUG = os.environ.get("SGS_SG_DEBUG", "")
+
+
+class _Captured:
+    __slots__ = ("key", "sampled", "g1", "g2l", "g2r", "cbuf", "loss", "loss_l", "loss_r", "grads", "grads_l", "grads_r",
+                 "keep")
+
+
+def _batch_key(batch):
+    return (batch.x.data_ptr(), batch.edge_index.data_ptr(), batch.y.data_ptr(), batch.train_mask.data_ptr(),
+            batch.prob.data_ptr() if getattr(batch, "prob", None) is not None else 0, batch.edge_index.shape[1],
+            batch.x.shape[0])
+
+
+class StepGraphs:
+    """Per-model registry of captured partition steps."""
+
+    def __init__(self, model, pipeline, args, criterion, q, use_checkpoint):
+        self.model = model
+        self.pipeline = pipeline
+        self.args = args
+        self.criterion = criterion
+        self.q = q
+        self.use_checkpoint = use_checkpoint
+        self.params = [p for p in model.parameters()]
+        self.device = self.params[0].device
+        self.epoch_word = torch.zeros(1, dtype=torch.int64, device=self.device)
+        # warm-up visits and captures share one side stream: autograd stamps every node (AccumulateGrad included)
+        # with the stream it was created on, and a capture must not meet nodes from the legacy default stream
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.table = {}          # batch key -> _Captured | "seen"
+        self.cfg = self._config_key()
+
+    def _config_key(self):
+        a = self.args
+        return (self.pipeline, bool(a.conditional), bool(a.sparse_edge_mlp), a.reg1 == True, a.reg2 == True,   # noqa: E712
+                float(a.regularizer1_coef), float(a.consist_reg_coef), float(a.degree_bias_coef), int(self.q),
+                bool(self.use_checkpoint), tuple(p.data_ptr() for p in self.params))
+
+    @classmethod
+    def attach(cls, model, pipeline, args, criterion, q, use_checkpoint):
+        sg = getattr(model, "_sgs_stepgraphs", None)
+        fresh = cls(model, pipeline, args, criterion, q, use_checkpoint) if sg is None else None
+        if sg is not None:
+            sg.args, sg.criterion = args, criterion
+            if (sg.pipeline, sg.q, sg.use_checkpoint) != (pipeline, q, use_checkpoint) or sg._config_key() != sg.cfg:
+                fresh = cls(model, pipeline, args, criterion, q, use_checkpoint)     # settings changed: drop old captures
+        if fresh is not None:
+            sg = model._sgs_stepgraphs = fresh
+        ops.set_rng_epoch_buffer(sg.epoch_word)
+        ops.pin_workspaces(True)
+        return sg
+
+    def release(self):
+        ops.set_rng_epoch_buffer(None)
+
+    # ------------------------------------------------------------------ capture
+    def _grads(self):
+        return {i: p.grad for i, p in enumerate(self.params) if p.grad is not None}
+
+    def _clear_grads(self):
+        for p in self.params:
+            p.grad = None
+
+    def _capture(self, batch, key) -> _Captured:
+        from .training import _ce, learned_loss, sampled_forward
+        a = self.args
+        c = _Captured()
+        c.key = key
+        c.sampled = batch.edge_index.shape[1] > self.q
+        self._clear_grads()
+        torch.cuda.synchronize()
+        c.g1 = torch.cuda.CUDAGraph()
+        for mod in self.model.modules():               # no memoised x W^T from an eager step may leak into a capture
+            if hasattr(mod, "_lin_cache"):
+                mod._lin_cache = None
+        if not c.sampled:
+            with torch.cuda.graph(c.g1, stream=self.stream):
+                self.epoch_word.add_(1)
+                out = self.model(batch, batch.edge_index)
+                c.loss = _ce(self.criterion, out, batch)
+                c.loss.backward()
+            c.grads = self._grads()
+            c.loss = c.loss.detach()
+            self._clear_grads()
+            return c
+        with torch.cuda.graph(c.g1, stream=self.stream):
+            self.epoch_word.add_(1)
+            st = sampled_forward(self.pipeline, a, self.model, batch, self.q, self.use_checkpoint)
+        pool = c.g1.pool() if _DEBUG != "nopool" else None
+        c.cbuf = st.cbuf
+        # static views of the replay's own draws and outputs (private-pool memory is never reused after the
+        # capture, so holding them costs nothing); tests recompute the step eagerly from these
+        c.keep = dict(rsei=st.rsei, eid=st.smp.eid, sampled_edge_index=st.sampled_edge_index,
+                      edge_probs_full=st.edge_probs_full.detach(), w=st.edge_probs_for_loss.detach(),
+                      learned_out=st.learned_out.detach(),
+                      random_out=None if st.random_out is None else st.random_out.detach())
+        c.g2l = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(c.g2l, stream=self.stream, **({"pool": pool} if pool is not None else {})):
+            loss_l = learned_loss(a, self.criterion, st, batch)
+            loss_l.backward(retain_graph=st.random_out is not None)
+        c.grads_l = self._grads()
+        c.loss_l = loss_l.detach()
+        self._clear_grads()
+        c.g2r = None
+        if st.random_out is not None:
+            c.g2r = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(c.g2r, stream=self.stream, **({"pool": pool} if pool is not None else {})):
+                loss_r = _ce(self.criterion, st.random_out, batch)
+                loss_r.backward()
+            c.grads_r = self._grads()
+            c.loss_r = loss_r.detach()
+            self._clear_grads()
+        return c
+
+    # ------------------------------------------------------------------ one step
+    def _set_grads(self, grads):
+        for i, p in enumerate(self.params):
+            p.grad = grads.get(i)
+
+    def _eager(self, batch):
+        """First visit: the same segments, uncaptured."""
+        from .training import _ce, learned_loss, sampled_forward
+        a = self.args
+        if batch.edge_index.shape[1] <= self.q:
+            loss = _ce(self.criterion, self.model(batch, batch.edge_index), batch)
+            loss.backward()
+            return loss.detach(), None
+        st = sampled_forward(self.pipeline, a, self.model, batch, self.q, self.use_checkpoint)
+        won = True
+        if a.conditional:
+            cnt = st.cbuf.tolist()
+            won = cnt[0] > cnt[2]
+        # warm-up must touch every kernel / library code path either capture will record (lazy code-object
+        # loads and first-use attribute calls are not capturable): run the branch the gate rejected first
+        if a.conditional:
+            other = _ce(self.criterion, st.random_out, batch) if won else learned_loss(a, self.criterion, st, batch)
+            other.backward(retain_graph=True)
+            self._clear_grads()
+        loss = learned_loss(a, self.criterion, st, batch) if won else _ce(self.criterion, st.random_out, batch)
+        loss.backward()
+        return loss.detach(), won
+
+    def step(self, batch, epoch):
+        """Runs forward + backward of one partition step; leaves `.grad` set.  Returns (loss, learned_won) with
+        learned_won None for partitions that are not sampled (E_b <= q)."""
+        key = _batch_key(batch)
+        c = self.table.get(key)
+        if c is None:
+            self.table[key] = "seen"
+            cur = torch.cuda.current_stream()
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                r = self._eager(batch)
+            cur.wait_stream(self.stream)
+            return r
+        if c == "seen":
+            c = self.table[key] = self._capture(batch, key)
+        if not c.sampled:
+            c.g1.replay()
+            self._set_grads(c.grads)
+            return c.loss, None
+        c.g1.replay()
+        won = True
+        if c.cbuf is not None:
+            cnt = c.cbuf.tolist()                      # the step's one host read-back (gate)
+            won = cnt[0] > cnt[2]
+        if won:
+            c.g2l.replay()
+            self._set_grads(c.grads_l)
+            return c.loss_l, True
+        c.g2r.replay()
+        self._set_grads(c.grads_r)
+        return c.loss_r, False

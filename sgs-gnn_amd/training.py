@@ -47,6 +47,76 @@ def _has_train_nodes(batch) -> bool:
     return flag
 
 
+class SampledForward:
+    """Everything the sampled step's forward leaves behind for the gate and the two possible backwards."""
+    __slots__ = ("rsei", "edge_probs_full", "smp", "sampled_edge_index", "edge_probs_for_loss", "learned_out",
+                 "random_out", "cbuf")
+
+
+def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise=None) -> SampledForward:
+    """training_hybrid.py:44-101 (ST 41-90, TP 41-92) up to the gate's inputs: prior draw, pass-1 scores, learned
+    draw, encoder over the learned graph, encoder over the random graph, the two correct-counts (device side).
+    No host read-back in here, so the whole segment can be captured into a HIP graph (stepgraph.py)."""
+    noise = noise or {}
+    st = SampledForward()
+    N = batch.x.shape[0]
+    scorer = model.edge_prob_mlp
+
+    st.rsei = None
+    if args.conditional or args.sparse_edge_mlp:                      # K0: prior-only draw
+        rs = draw_prior(batch.prob, batch.edge_index, q, noise=noise.get("prior"))
+        st.rsei = rs.edge_index
+
+    # pass 1: score every edge (hybrid / ST with grad, two-pass without)
+    if pipeline == "two_pass":
+        with torch.no_grad():
+            st.edge_probs_full = scorer(batch.x, batch.edge_index, st.rsei).squeeze()
+    elif pipeline == "hybrid":
+        st.edge_probs_full = scorer(batch.x, batch.edge_index, st.rsei, use_checkpoint=use_checkpoint).squeeze()
+    else:
+        st.edge_probs_full = scorer(batch.x, batch.edge_index, st.rsei).squeeze()
+    pass1_active = getattr(scorer, "last_active", None)
+
+    # K2+K3: learned draw on detached probabilities, compacted columns in edge order
+    st.smp = smp = draw_learned(batch.prob, st.edge_probs_full, batch.edge_index, q, args.degree_bias_coef,
+                                noise=noise.get("sample"))
+    st.sampled_edge_index = smp.edge_index
+    graph_s = ops.get_graph(smp.edge_index, N)
+
+    if pipeline == "hybrid":
+        # edge_probs_full[mask]: gradient reaches only the q sampled entries
+        if pass1_active is not None:
+            pass1_active.set(smp.eid, graph_s)
+        st.edge_probs_for_loss = st.edge_probs_full.index_select(0, smp.eid)
+    elif pipeline == "straight_through":
+        st.edge_probs_for_loss = ops.st_weights(st.edge_probs_full, batch.prob, args.degree_bias_coef, smp.stats, smp.eid)
+    else:
+        # pass 3: re-score the sampled edges with grad; encoder over the learned graph
+        st.edge_probs_for_loss = scorer(batch.x, smp.edge_index).squeeze()
+    st.learned_out = model(batch, smp.edge_index, st.edge_probs_for_loss)
+
+    st.random_out = None
+    st.cbuf = None
+    if args.conditional:
+        st.random_out = model(batch, st.rsei)
+        st.cbuf = torch.empty(5, dtype=torch.int32, device=st.learned_out.device)
+        ops.masked_correct(st.learned_out, batch.y, batch.train_mask, out=st.cbuf[0:2])
+        ops.masked_correct(st.random_out, batch.y, batch.train_mask, out=st.cbuf[2:4])
+    return st
+
+
+def learned_loss(args, criterion, st: SampledForward, batch):
+    """training_hybrid.py:105-133: CE + reg1 (BCE on same-class labels) + reg2 (cosine consistency)."""
+    loss = _ce(criterion, st.learned_out, batch)
+    c1 = args.regularizer1_coef if args.reg1 == True else 0.0      # noqa: E712 (as the reference)
+    c2 = args.consist_reg_coef if args.reg2 == True else 0.0       # noqa: E712
+    if c1 != 0.0 or c2 != 0.0:
+        reg, _ = ops.edge_regularizers(st.edge_probs_for_loss, st.learned_out, st.sampled_edge_index, batch.y,
+                                       batch.train_mask, c1, c2)
+        loss = loss + reg
+    return loss
+
+
 def train(args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, optimizer, criterion, cluster_loader,
           q=500, alternate_frequency=1):
     """training.py:6-49: dispatch on args.pipeline (default two_pass)."""
@@ -77,10 +147,6 @@ def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edg
     if pipeline == "hybrid" and epoch == 0:
         print(f"[hybrid] checkpoint={'on' if use_checkpoint else 'off'}")       # training_hybrid.py:12-13
     model.train()
-    total_loss = None
-    temperature = 1.0
-    condtional_update = 0
-    total_update = 0
     noise = getattr(args, "_sgs_noise", None) or {}
     trace = getattr(args, "_sgs_trace", None)
     sync = None
@@ -88,7 +154,26 @@ def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edg
         sync = getattr(model, "_sgs_gradsync", None)
         if sync is None:
             sync = model._sgs_gradsync = GradSync(model.parameters())
+    graphs = None
+    if (getattr(args, "sgs_hipgraph", False) and mode == 'learned' and sync is None and not noise and trace is None
+            and _fused_ce_ok(criterion)):
+        from .stepgraph import StepGraphs               # opt-in: replay captured HIP graphs of each partition's step
+        graphs = StepGraphs.attach(model, pipeline, args, criterion, q, use_checkpoint)
 
+    try:
+        return _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, optimizer,
+                           criterion, cluster_loader, q, device, mode, use_checkpoint, noise, trace, sync, graphs)
+    finally:
+        if graphs is not None:
+            graphs.release()
+
+
+def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, optimizer, criterion,
+                cluster_loader, q, device, mode, use_checkpoint, noise, trace, sync, graphs):
+    total_loss = None
+    temperature = 1.0
+    condtional_update = 0
+    total_update = 0
     for batch in cluster_loader:
         if not _has_train_nodes(batch):
             continue
@@ -97,57 +182,26 @@ def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edg
         optimizer_gnn.zero_grad()
 
         if mode == 'learned':
-            if batch.edge_index.shape[1] > q:
-                batch = batch.to(device)
-                N = batch.x.shape[0]
-                scorer = model.edge_prob_mlp
-
-                rsei = None
-                if args.conditional or args.sparse_edge_mlp:                      # K0: prior-only draw
-                    rs = draw_prior(batch.prob, batch.edge_index, q, noise=noise.get("prior"))
-                    rsei = rs.edge_index
-
-                # pass 1: score every edge (hybrid / ST with grad, two-pass without)
-                if pipeline == "two_pass":
-                    with torch.no_grad():
-                        edge_probs_full = scorer(batch.x, batch.edge_index, rsei).squeeze()
-                elif pipeline == "hybrid":
-                    edge_probs_full = scorer(batch.x, batch.edge_index, rsei, use_checkpoint=use_checkpoint).squeeze()
-                else:
-                    edge_probs_full = scorer(batch.x, batch.edge_index, rsei).squeeze()
-                pass1_active = getattr(scorer, "last_active", None)
-
-                t_init, t_min = args.t_init, args.t_min
-                r = (t_init - t_min) / max_epoch
-                temperature = max(t_min, t_init - epoch * r)                      # returned, never used by the sampler
-
-                # K2+K3: learned draw on detached probabilities, compacted columns in edge order
-                smp = draw_learned(batch.prob, edge_probs_full, batch.edge_index, q, args.degree_bias_coef,
-                                   noise=noise.get("sample"))
-                sampled_edge_index = smp.edge_index
-                graph_s = ops.get_graph(sampled_edge_index, N)
-
-                if pipeline == "hybrid":
-                    # edge_probs_full[mask]: gradient reaches only the q sampled entries
-                    if pass1_active is not None:
-                        pass1_active.set(smp.eid, graph_s)
-                    edge_probs_for_loss = edge_probs_full.index_select(0, smp.eid)
-                elif pipeline == "straight_through":
-                    edge_probs_for_loss = ops.st_weights(edge_probs_full, batch.prob, args.degree_bias_coef, smp.stats, smp.eid)
-                else:
-                    # pass 3: re-score the sampled edges with grad; encoder over the learned graph
-                    edge_probs_for_loss = scorer(batch.x, sampled_edge_index).squeeze()
-                learned_out = model(batch, sampled_edge_index, edge_probs_for_loss)
+            batch = batch.to(device)
+            if graphs is not None:
+                # opt-in HIP-graph replay of the step's device work (stepgraph.py); same segments as below
+                loss, learned_won = graphs.step(batch, epoch)
+                if learned_won is not None:
+                    r = (args.t_init - args.t_min) / max_epoch
+                    temperature = max(args.t_min, args.t_init - epoch * r)
+                    if learned_won:
+                        condtional_update += 1
+                        optimizer_edge_prob.step()
+                optimizer_gnn.step()
+            elif batch.edge_index.shape[1] > q:
+                st = sampled_forward(pipeline, args, model, batch, q, use_checkpoint, noise)
+                temperature = max(args.t_min, args.t_init - epoch * ((args.t_init - args.t_min) / max_epoch))   # returned, never used by the sampler
 
                 update_edge_mlp = True
-                random_out = None
                 counts = None
                 any_learned = False
                 if args.conditional:
-                    random_out = model(batch, rsei)
-                    cbuf = torch.empty(5, dtype=torch.int32, device=learned_out.device)
-                    ops.masked_correct(learned_out, batch.y, batch.train_mask, out=cbuf[0:2])
-                    ops.masked_correct(random_out, batch.y, batch.train_mask, out=cbuf[2:4])
+                    cbuf = st.cbuf
                     if sync is not None:            # N > 1: does ANY rank's gate choose "learned"? (device-side, no extra sync)
                         cbuf[4:5] = sync.any_learned((cbuf[0:1] > cbuf[2:3]).to(torch.int32))
                     counts = cbuf.tolist()                                         # the step's one host read-back
@@ -157,24 +211,17 @@ def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edg
                     update_edge_mlp = counts[0][0] > counts[1][0]
 
                 if sync is not None and not args.conditional:
-                    sync.any_learned(torch.ones(1, dtype=torch.int32, device=learned_out.device))   # keep the collective in lock-step
+                    sync.any_learned(torch.ones(1, dtype=torch.int32, device=st.learned_out.device))   # keep the collective in lock-step
                 if update_edge_mlp:
                     condtional_update += 1
-                    loss = _ce(criterion, learned_out, batch)
-                    c1 = args.regularizer1_coef if args.reg1 == True else 0.0      # noqa: E712 (as the reference)
-                    c2 = args.consist_reg_coef if args.reg2 == True else 0.0       # noqa: E712
-                    reg_terms = None
-                    if c1 != 0.0 or c2 != 0.0:
-                        reg, reg_terms = ops.edge_regularizers(edge_probs_for_loss, learned_out, sampled_edge_index, batch.y,
-                                                               batch.train_mask, c1, c2)
-                        loss = loss + reg
+                    loss = learned_loss(args, criterion, st, batch)
                     loss.backward()
                     if sync is not None:
                         sync.sync()
                     optimizer_edge_prob.step()
                     optimizer_gnn.step()
                 else:
-                    loss = _ce(criterion, random_out, batch)
+                    loss = _ce(criterion, st.random_out, batch)
                     loss.backward()
                     if sync is not None:
                         sync.sync()
@@ -183,12 +230,11 @@ def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edg
                     optimizer_gnn.step()
 
                 if trace is not None:
-                    trace.update(rsei=rsei, edge_probs_full=edge_probs_full.detach(), sample=smp,
-                                 w=edge_probs_for_loss.detach(), learned_out=learned_out.detach(),
-                                 random_out=None if random_out is None else random_out.detach(), counts=counts,
+                    trace.update(rsei=st.rsei, edge_probs_full=st.edge_probs_full.detach(), sample=st.smp,
+                                 w=st.edge_probs_for_loss.detach(), learned_out=st.learned_out.detach(),
+                                 random_out=None if st.random_out is None else st.random_out.detach(), counts=counts,
                                  update_edge_mlp=update_edge_mlp, loss=loss.detach())
             else:
-                batch = batch.to(device)
                 out = model(batch, batch.edge_index)
                 loss = _ce(criterion, out, batch)
                 loss.backward()
@@ -231,7 +277,8 @@ def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edg
         else:
             raise ValueError("Invalid mode. Choose 'learned', 'random', or 'full'.")
 
-        total_loss = loss.detach() if total_loss is None else total_loss + loss.detach()
+        # (.clone(): under HIP-graph replay `loss` is a static buffer the next replay overwrites)
+        total_loss = loss.detach().clone() if total_loss is None else total_loss + loss.detach()
 
     mean_loss = (float(total_loss) if total_loss is not None else 0.0) / len(cluster_loader)
     return mean_loss, temperature, condtional_update, total_update

@@ -171,3 +171,43 @@ def test_full_size_properties(ops):
         assert torch.equal(r.eid, torch.nonzero(r.mask).squeeze(1))
         assert float(r.keys[r.mask].min()) >= float(r.keys[~r.mask].max())
         assert torch.equal(r.edge_index, ei[:, r.mask])
+
+
+def test_rng_epoch_buffer_shifts_every_seed(ops):
+    """sgs_rng_set_epoch_buffer: epoch 0 == no buffer; epoch k == seed + 0x9E3779B97F4A7C15*k (mod 2^64),
+    for the noise helper, the dropout helper, the fused sampler draw and the SpMM dropout epilogue."""
+    G = 0x9E3779B97F4A7C15
+    seed, E = 1234, 5000
+    base_noise = ops.exp_noise(seed, 7, E, DEV)
+    base_keep = ops.dropout_keep(seed, 3, 37, 64, 0.3, DEV)
+    epoch = torch.zeros(1, dtype=torch.int64, device=DEV)
+    try:
+        ops.set_rng_epoch_buffer(epoch)
+        assert torch.equal(ops.exp_noise(seed, 7, E, DEV), base_noise)
+        assert torch.equal(ops.dropout_keep(seed, 3, 37, 64, 0.3, DEV), base_keep)
+        epoch.fill_(5)
+        n5 = ops.exp_noise(seed, 7, E, DEV)
+        k5 = ops.dropout_keep(seed, 3, 37, 64, 0.3, DEV)
+        # a fused draw under epoch 5 == explicit-noise draw with that epoch's noise
+        torch.manual_seed(0)
+        p = torch.rand(E, device=DEV)
+        ei = torch.randint(0, 100, (2, E), device=DEV)
+        r_epoch = ops.sample_topq(ops.SAMPLE_LEARNED, p, None, 0.0, 1000, ei, seed=seed, stream_id=7)
+        # SpMM dropout epilogue under epoch 5
+        import sgs_gnn_amd
+        g = ops.get_graph(ei[:, :2000].contiguous(), 100)
+        nm = ops.gcn_norm(g)
+        X = torch.randn(100, 64, device=DEV)
+        y_epoch = ops.gcn_propagate(X, nm, None, ops.ACT_RELU_DROPOUT, 0.3, seed, 3)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_rng_epoch_buffer(None)
+    s5 = (seed + G * 5) % (1 << 64)
+    assert torch.equal(n5, ops.exp_noise(s5, 7, E, DEV))
+    assert torch.equal(k5, ops.dropout_keep(s5, 3, 37, 64, 0.3, DEV))
+    assert not torch.equal(n5, base_noise)
+    r_ref = ops.sample_topq(ops.SAMPLE_LEARNED, p, None, 0.0, 1000, ei, noise=n5)
+    assert torch.equal(r_epoch.mask, r_ref.mask)
+    y_ref = ops.gcn_propagate(X, nm, None, ops.ACT_RELU_DROPOUT, 0.3, s5, 3)
+    assert torch.equal(y_epoch, y_ref)
+    assert not torch.equal(y_epoch, ops.gcn_propagate(X, nm, None, ops.ACT_RELU_DROPOUT, 0.3, seed, 3))

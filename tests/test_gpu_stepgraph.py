@@ -1,0 +1,181 @@
+"""GPU: opt-in HIP-graph replay of the partition step (stepgraph.py) against the eager path.
+
+Replays draw their own noise (RNG epoch word), so the sampled step is checked by recomputing it eagerly
+from the replay's own draws (dropout 0); unsampled partitions must match eager training bit for bit."""
+import argparse
+import copy
+
+import pytest
+import torch
+
+import os
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("SGS_TEST_HIPGRAPH") != "1",
+                                 reason="HIP-graph replay is experimental (set SGS_TEST_HIPGRAPH=1)")]
+DEV = "cuda:0"
+
+
+def _args(**kw):
+    a = argparse.Namespace(device=DEV, mode="learned", pipeline="hybrid", edge_mlp_type="GCN", conditional=True,
+                           sparse_edge_mlp=True, t_init=0.7, t_min=0.5, degree_bias_coef=0.3, reg1=True, reg2=True,
+                           regularizer1_coef=1.0, consist_reg_coef=0.5, hybrid_checkpoint=False, drop_rate=0.0, lr=1e-2)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def _setup(S, p_drop, seed=3):
+    torch.manual_seed(seed)
+    S.fix_seeds(seed)
+    m = S.GNNModel(24, 32, 5, dropout_prob=p_drop, edge_mlp_type="GCN").to(DEV)
+    og = torch.optim.Adam([p for n, p in m.named_parameters() if "gcn" in n], lr=1e-2)
+    oe = torch.optim.Adam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-2)
+    return m, og, oe
+
+
+def _batches(S, sizes, n=120, seed=11):
+    return [S.synthetic_graph(n, E, 24, 5, seed=seed + i, device=DEV) for i, E in enumerate(sizes)]
+
+
+def test_unsampled_partitions_replay_equals_eager_bitwise():
+    import sgs_gnn_amd as S
+    crit = torch.nn.CrossEntropyLoss()
+    bs = _batches(S, [900, 1500, 700])
+    q = 5000                                           # every partition below q: no draws, dropout 0 -> deterministic
+    m1, og1, oe1 = _setup(S, 0.0)
+    m2, og2, oe2 = _setup(S, 0.0)
+    m2.load_state_dict(copy.deepcopy(m1.state_dict()))
+    r1, r2 = [], []
+    for ep in range(4):                                # epoch 0 eager warm-up, 1 capture, 2-3 replay
+        r1.append(S.train(_args(), ep, 10, m1, og1, oe1, None, crit, bs, q=q))
+        r2.append(S.train(_args(sgs_hipgraph=True), ep, 10, m2, og2, oe2, None, crit, bs, q=q))
+    assert r1 == r2
+    for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p1, p2), n1
+    assert len(m2._sgs_stepgraphs.table) == 3
+    # the RNG epoch word is registered only while a graph-mode train() runs
+    assert S.ops._rng_epoch is None
+
+
+@pytest.mark.parametrize("pipeline", ["hybrid", "straight_through", "two_pass"])
+def test_sampled_replay_matches_eager_recomputation_from_its_own_draws(pipeline):
+    import sgs_gnn_amd as S
+    from sgs_gnn_amd.stepgraph import StepGraphs
+    from sgs_gnn_amd.training import _ce, learned_loss, SampledForward
+    ops = S.ops
+    crit = torch.nn.CrossEntropyLoss()
+    b = _batches(S, [4000])[0]
+    q, N = 800, b.x.shape[0]
+    m, og, oe = _setup(S, 0.0)
+    a = _args(pipeline=pipeline)
+    sg = StepGraphs.attach(m, pipeline, a, crit, q, False)
+    try:
+        sg.step(b, 0)                                  # eager warm-up visit
+        for p in m.parameters():
+            p.grad = None
+        sg.step(b, 0)                                  # capture + first replay
+        c = sg.table[next(iter(sg.table))]
+        params = list(m.parameters())
+        seen = []
+        for it in range(3):
+            c.g1.replay()
+            k = {n: (None if t is None else t.clone()) for n, t in c.keep.items()}
+            cnt = c.cbuf.tolist()
+            seen.append(k["eid"].clone())
+            c.g2l.replay()
+            gl = {i: g.clone() for i, g in c.grads_l.items()}
+            ll = c.loss_l.clone()
+            c.g2r.replay()
+            gr = {i: g.clone() for i, g in c.grads_r.items()}
+            lr_ = c.loss_r.clone()
+            torch.cuda.synchronize()
+            assert k["eid"].numel() == q and bool((k["eid"][1:] > k["eid"][:-1]).all())
+            assert torch.equal(k["sampled_edge_index"], b.edge_index[:, k["eid"]])
+
+            # eager recomputation from the replay's draws (epoch word irrelevant at dropout 0)
+            for p in params:
+                p.grad = None
+            sc = m.edge_prob_mlp
+            st = SampledForward()
+            st.rsei, st.sampled_edge_index = k["rsei"], k["sampled_edge_index"]
+            if pipeline == "two_pass":
+                with torch.no_grad():
+                    pf = sc(b.x, b.edge_index, k["rsei"]).squeeze()
+            else:
+                pf = sc(b.x, b.edge_index, k["rsei"]).squeeze()
+            assert torch.allclose(pf.detach(), k["edge_probs_full"], rtol=1e-5, atol=1e-6)
+            if pipeline == "hybrid":
+                act = getattr(sc, "last_active", None)
+                if act is not None:
+                    act.set(k["eid"], ops.get_graph(k["sampled_edge_index"], N))
+                w = pf.index_select(0, k["eid"])
+            elif pipeline == "two_pass":
+                w = sc(b.x, k["sampled_edge_index"]).squeeze()
+            else:
+                w = None
+            if w is not None:
+                st.edge_probs_for_loss = w
+                assert torch.allclose(w.detach(), k["w"], rtol=1e-5, atol=1e-6)
+                st.learned_out = m(b, k["sampled_edge_index"], w)
+                assert torch.allclose(st.learned_out.detach(), k["learned_out"], rtol=1e-4, atol=1e-5)
+                loss = learned_loss(a, crit, st, b)
+                loss.backward()
+                assert torch.allclose(loss.detach(), ll, rtol=1e-5, atol=1e-6)
+                for i, p in enumerate(params):
+                    if p.grad is None:
+                        assert i not in gl
+                    else:
+                        assert torch.allclose(p.grad, gl[i], rtol=2e-4, atol=2e-6), i
+            # random branch
+            for p in params:
+                p.grad = None
+            ro = m(b, k["rsei"])
+            assert torch.allclose(ro.detach(), k["random_out"], rtol=1e-4, atol=1e-5)
+            lr2 = _ce(crit, ro, b)
+            lr2.backward()
+            assert torch.allclose(lr2.detach(), lr_, rtol=1e-5, atol=1e-6)
+            for i, p in enumerate(params):
+                if p.grad is None:
+                    assert i not in gr
+                else:
+                    assert torch.allclose(p.grad, gr[i], rtol=2e-4, atol=2e-6), i
+            want = [int(x) for x in ops.masked_correct(k["learned_out"], b.y, b.train_mask).tolist()]
+            assert cnt[0:2] == want
+        # every replay drew a different edge set; resetting the epoch word reproduces a replay exactly
+        assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+        e = int(sg.epoch_word.item())
+        sg.epoch_word.fill_(e - 1)
+        c.g1.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(c.keep["eid"], seen[2])
+    finally:
+        sg.release()
+
+
+def test_graph_mode_training_with_dropout_runs_and_learns():
+    import sgs_gnn_amd as S
+    crit = torch.nn.CrossEntropyLoss()
+    bs = _batches(S, [5000, 900, 4000], n=150)
+    q = 1000
+    m, og, oe = _setup(S, 0.3)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    a = _args(sgs_hipgraph=True)
+    losses, conds = [], 0
+    for ep in range(12):
+        loss, _, cond, tot = S.train(a, ep, 12, m, og, oe, None, crit, bs, q=q)
+        assert tot == 3 and 0 <= cond <= 2
+        conds += cond
+        losses.append(loss)
+    assert all(torch.isfinite(torch.tensor(losses)))
+    assert losses[-1] < losses[0]
+    for n, p in m.named_parameters():
+        assert torch.isfinite(p).all()
+    moved = [n for n, p in m.named_parameters() if not torch.equal(p, before[n])]
+    assert any("gcn1" in n for n in moved)
+    if conds:
+        assert any("fc1" in n for n in moved)
+    # eager evaluation afterwards is unaffected by graph mode
+    args_e = argparse.Namespace(degree_bias_coef=0.3, num_samples_eval=2)
+    f1 = S.evaluate(args_e, m, bs, DEV, q=q, mode="learned")
+    assert all(0.0 <= v <= 1.0 for v in f1)
