@@ -143,8 +143,8 @@ def main():
     ap.add_argument("--pool", type=int, default=12, help="distinct partition batches kept resident per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--score-variant", type=int, default=-1, help="scorer forward kernel for the timed steps (benchmarking A/B; -1 = library default)")
-    ap.add_argument("--hipgraph", type=int, default=0, help="1: replay each partition's step from captured HIP graphs (stepgraph.py); "
-                    "every pool partition is visited twice (eager, capture) before the W warm-up steps")
+    ap.add_argument("--hipgraph", type=int, default=1, help="1 (default): replay each partition's step from captured HIP graphs "
+                    "(stepgraph.py; every pool partition is visited twice -- eager, capture -- before the W warm-up steps); 0: eager launches")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -172,7 +172,7 @@ def main():
     # partition pool (per rank: its own shard of the stream), resident in HBM before timing
     pool = S.reddit_partition_stream(num_parts=a.pool, seed=1000 + rank, nfeat=NFEAT, ncls=NCLS, n=N_NODES, q=Q, device=device)
     warm = [pool[i % len(pool)] for i in range(a.warmup)]
-    if a.hipgraph and world == 1:
+    if a.hipgraph:
         args.sgs_hipgraph = True
         warm = list(pool) * 2 + warm
     timed = [pool[i % len(pool)] for i in range(a.steps)]

@@ -706,7 +706,7 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
     if (g_score_variant == 2 && H % 64 == 0 && N > 0) {
         float* zpart = cv.take<float>(2 * static_cast<size_t>(E));
         unsigned int* ctr = cv.take<unsigned int>(64);
-        SGS_HIP_OK(hipMemsetAsync(ctr, 0, 256, stream));
+        if (int rc = zero_async(ctr, 256, stream)) return rc;
         hipLaunchKernelGGL(pack_w1a_stream, dim3(cdiv(H * H, kT)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);
         hipLaunchKernelGGL(pack_codes_eo, dim3(cdiv(N * H, kT)), dim3(kT), 0, stream, codes, N, static_cast<int>(H), Ceo);
         constexpr int TH = 768;                                             // 12 waves = 3 per SIMD (168-register budget; 16 waves spill)

@@ -697,8 +697,8 @@ int sgs_graph_build(const int64_t* edge_index, int64_t n_edges, int64_t N, int32
     int* cur_out = cv.take<int>(N + 1);
     int* tmp_in = cv.take<int>(n_edges + 1);
     int* tmp_out = cv.take<int>(n_edges + 1);
-    SGS_HIP_OK(hipMemsetAsync(cnt_in, 0, 2 * carve_bytes(N + 1, 4), stream));      // cnt_in + cnt_out are adjacent
-    SGS_HIP_OK(hipMemsetAsync(loop_eid, 0xff, static_cast<size_t>(N) * 4, stream));  // -1
+    // cnt_in + cnt_out are adjacent -> 0; loop_eid -> -1 (one kernel launch, not memset nodes: see zero_async)
+    if (int rc = fill2_async(cnt_in, 2 * carve_bytes(N + 1, 4), 0u, loop_eid, static_cast<size_t>(N) * 4, 0xFFFFFFFFu, stream)) return rc;
     const bool small_n = N <= kLdsNodes;
     if (n_edges > 0) {
         if (small_n)

@@ -220,7 +220,7 @@ int sgs_masked_correct(const float* logits, int64_t N, int64_t C, const int64_t*
                        int32_t* correct, sgs_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     SGS_REQUIRE(N >= 0 && C > 0 && correct, SGS_EINVAL, "sgs_masked_correct: bad arguments");
-    SGS_HIP_OK(hipMemsetAsync(correct, 0, 8, stream));
+    if (int rc = zero_async(correct, 8, stream)) return rc;
     if (N == 0) return SGS_OK;
     SGS_REQUIRE(logits && y && train_mask, SGS_EINVAL, "sgs_masked_correct: null pointer");
     hipLaunchKernelGGL(masked_correct, dim3(cdiv(N * 64, kT)), dim3(kT), 0, stream, logits, N, C, y, train_mask, correct);

@@ -523,9 +523,8 @@ int sgs_sample_topq(int mode, const float* p, const float* prior, double degree_
     SelectState* st = cv.take<SelectState>(1);
     uint2* cnt = cv.take<uint2>(nblk + 1);
 
-    SGS_HIP_OK(hipMemsetAsync(scal, 0, 16, stream));
-    SGS_HIP_OK(hipMemsetAsync(hist, 0, kBins * 4, stream));
-    SGS_HIP_OK(hipMemsetAsync(st, 0, sizeof(SelectState), stream));
+    // scal, hist and st are adjacent carvings: one zeroing launch (a kernel, not a memset node: see zero_async)
+    if (int rc = zero_async(scal, static_cast<size_t>(reinterpret_cast<char*>(st + 1) - reinterpret_cast<char*>(scal)), stream)) return rc;
 
     const dim3 grid(static_cast<unsigned>(nblk)), blk(kThreads);
     if (mode == SGS_SAMPLE_LEARNED) {
@@ -722,7 +721,7 @@ int sgs_st_weights_bwd(const float* p, const float* prior, double degree_bias_co
     float* S = cv.take<float>(4);
     const float one_minus_c = static_cast<float>(1.0 - degree_bias_coef), c = static_cast<float>(degree_bias_coef);
     const float a = prior ? one_minus_c : 1.0f;
-    SGS_HIP_OK(hipMemsetAsync(S, 0, 16, stream));
+    if (int rc = zero_async(S, 16, stream)) return rc;
     if (q > 0) {
         if (prior)
             hipLaunchKernelGGL(st_bwd_partial<true>, dim3(nblk), dim3(kThreads), 0, stream, p, prior, one_minus_c, c, stats,

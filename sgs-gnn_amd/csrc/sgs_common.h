@@ -49,6 +49,15 @@ __device__ __forceinline__ uint64_t fold_epoch(uint64_t seed, const uint64_t* __
     return epoch ? seed + 0x9E3779B97F4A7C15ULL * (*epoch) : seed;
 }
 
+// ---------------------------------------------------------------- zero fill as a KERNEL
+// hipMemsetAsync is deliberately not used anywhere in this library: captured into a HIP graph it becomes a memset
+// node, and on replay (ROCm 7.2 / gfx950) those were observed not to stay ordered with the neighbouring kernel nodes
+// (the sampler's select state was cleared after the kernels that fill it).  A kernel node has no such problem and
+// several adjacent scratch words are cleared by one launch.  `p` 4-byte aligned, `bytes` a multiple of 4.
+int zero_async(void* p, size_t bytes, hipStream_t stream);
+// two spans in one launch: 32-bit word `v1` over [p1, p1+bytes1), `v2` over [p2, p2+bytes2)
+int fill2_async(void* p1, size_t bytes1, uint32_t v1, void* p2, size_t bytes2, uint32_t v2, hipStream_t stream);
+
 // ---------------------------------------------------------------- workspace carving (256-B aligned)
 struct Carver {
     char* base;

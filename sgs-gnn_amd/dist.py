@@ -51,9 +51,11 @@ class GradSync:
             dist.all_reduce(learned_local, op=dist.ReduceOp.SUM)
         return learned_local
 
-    def sync(self) -> None:
+    def sync(self, all_random: bool = False) -> None:
         """Average all .grad tensors across ranks (missing grads count as zeros); afterwards every
-        parameter's .grad is a view of the shared bucket."""
+        parameter's .grad is a view of the shared bucket.  `all_random`: no rank took the learned branch this
+        step, so the parameters without a gradient here have none on any rank -- they keep `.grad = None` and
+        the optimisers skip them exactly as on one GPU (Adam with a zero gradient would still move them)."""
         if not is_parallel():
             return
         self._ensure(self.params[0].device)
@@ -70,5 +72,6 @@ class GradSync:
             torch._foreach_zero_(miss_v)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.div_(dist.get_world_size())
+        missing = {id(p) for p in self.params if p.grad is None} if all_random else ()
         for p, v in zip(self.params, self.views):
-            p.grad = v
+            p.grad = None if id(p) in missing else v

@@ -30,6 +30,7 @@ import torch
 from . import ops
 
 
+import gc
 import os
 _DEBUG = os.environ.get("SGS_SG_DEBUG", "")
 
@@ -96,9 +97,24 @@ class StepGraphs:
             p.grad = None
 
     def _capture(self, batch, key) -> _Captured:
+        # The cyclic collector must not run inside a capture: it may finalise objects whose destructors call into
+        # the runtime (an old CUDAGraph, a stream, an event), which is illegal while a stream is capturing.  Collect
+        # first (this also retires autograd nodes left over from eager steps), then hold the collector off.
+        was_enabled = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            return self._capture_segments(batch, key)
+        finally:
+            if was_enabled:
+                gc.enable()
+
+    def _capture_segments(self, batch, key) -> _Captured:
         from .training import _ce, learned_loss, sampled_forward
         a = self.args
         c = _Captured()
+        for name in _Captured.__slots__:
+            setattr(c, name, None)
         c.key = key
         c.sampled = batch.edge_index.shape[1] > self.q
         self._clear_grads()
@@ -151,57 +167,84 @@ class StepGraphs:
         for i, p in enumerate(self.params):
             p.grad = grads.get(i)
 
-    def _eager(self, batch):
-        """First visit: the same segments, uncaptured."""
-        from .training import _ce, learned_loss, sampled_forward
-        a = self.args
-        if batch.edge_index.shape[1] <= self.q:
-            loss = _ce(self.criterion, self.model(batch, batch.edge_index), batch)
-            loss.backward()
-            return loss.detach(), None
-        st = sampled_forward(self.pipeline, a, self.model, batch, self.q, self.use_checkpoint)
-        won = True
-        if a.conditional:
-            cnt = st.cbuf.tolist()
-            won = cnt[0] > cnt[2]
-        # warm-up must touch every kernel / library code path either capture will record (lazy code-object
-        # loads and first-use attribute calls are not capturable): run the branch the gate rejected first
-        if a.conditional:
-            other = _ce(self.criterion, st.random_out, batch) if won else learned_loss(a, self.criterion, st, batch)
-            other.backward(retain_graph=True)
-            self._clear_grads()
-        loss = learned_loss(a, self.criterion, st, batch) if won else _ce(self.criterion, st.random_out, batch)
-        loss.backward()
-        return loss.detach(), won
-
-    def step(self, batch, epoch):
-        """Runs forward + backward of one partition step; leaves `.grad` set.  Returns (loss, learned_won) with
-        learned_won None for partitions that are not sampled (E_b <= q)."""
+    def forward(self, batch) -> "StepHandle":
+        """Runs the step up to the gate (E_b > q) or completely (E_b <= q) and returns the handle the trainer
+        finishes the step with: `h.sampled`, `h.cbuf` (gate counts, device int32[5]) and `h.backward(learned)`."""
         key = _batch_key(batch)
         c = self.table.get(key)
-        if c is None:
+        if c is None:                                  # first visit: eager, on the capture stream
             self.table[key] = "seen"
-            cur = torch.cuda.current_stream()
-            self.stream.wait_stream(cur)
-            with torch.cuda.stream(self.stream):
-                r = self._eager(batch)
-            cur.wait_stream(self.stream)
-            return r
+            return _EagerHandle(self, batch)
         if c == "seen":
             c = self.table[key] = self._capture(batch, key)
-        if not c.sampled:
-            c.g1.replay()
-            self._set_grads(c.grads)
-            return c.loss, None
         c.g1.replay()
+        return _ReplayHandle(self, c)
+
+    def step(self, batch, epoch=0):
+        """Single-process convenience: forward, gate read-back, backward.  Returns (loss, learned_won | None)."""
+        h = self.forward(batch)
+        if not h.sampled:
+            return h.backward(None), None
         won = True
-        if c.cbuf is not None:
-            cnt = c.cbuf.tolist()                      # the step's one host read-back (gate)
+        if h.cbuf is not None:
+            cnt = h.cbuf.tolist()                      # the step's one host read-back (gate)
             won = cnt[0] > cnt[2]
-        if won:
+        return h.backward(won), won
+
+
+class _ReplayHandle:
+    __slots__ = ("sg", "c", "sampled", "cbuf")
+
+    def __init__(self, sg, c):
+        self.sg, self.c, self.sampled, self.cbuf = sg, c, c.sampled, c.cbuf
+
+    def backward(self, learned):
+        c, sg = self.c, self.sg
+        if not c.sampled:                              # the single graph already ran forward + backward
+            sg._set_grads(c.grads)
+            return c.loss
+        if learned:
             c.g2l.replay()
-            self._set_grads(c.grads_l)
-            return c.loss_l, True
+            sg._set_grads(c.grads_l)
+            return c.loss_l
         c.g2r.replay()
-        self._set_grads(c.grads_r)
-        return c.loss_r, False
+        sg._set_grads(c.grads_r)
+        return c.loss_r
+
+
+class _EagerHandle:
+    """First visit of a partition: the same segments launched eagerly on the capture stream (warm-up)."""
+    __slots__ = ("sg", "batch", "sampled", "cbuf", "st", "cur")
+
+    def __init__(self, sg, batch):
+        from .training import sampled_forward
+        self.sg, self.batch = sg, batch
+        self.sampled = batch.edge_index.shape[1] > sg.q
+        self.cbuf, self.st = None, None
+        self.cur = torch.cuda.current_stream()
+        sg.stream.wait_stream(self.cur)
+        if self.sampled:
+            with torch.cuda.stream(sg.stream):
+                self.st = sampled_forward(sg.pipeline, sg.args, sg.model, batch, sg.q, sg.use_checkpoint)
+            self.cur.wait_stream(sg.stream)
+            self.cbuf = self.st.cbuf
+
+    def backward(self, learned):
+        from .training import _ce, learned_loss
+        sg, a, batch, st = self.sg, self.sg.args, self.batch, self.st
+        sg.stream.wait_stream(self.cur)
+        with torch.cuda.stream(sg.stream):
+            if not self.sampled:
+                loss = _ce(sg.criterion, sg.model(batch, batch.edge_index), batch)
+            else:
+                # warm-up must touch every kernel / library code path either capture will record (lazy code-object
+                # loads and first-use attribute calls are not capturable): run the branch the gate rejected first
+                if st.random_out is not None:
+                    other = _ce(sg.criterion, st.random_out, batch) if learned else learned_loss(a, sg.criterion, st, batch)
+                    other.backward(retain_graph=True)
+                    sg._clear_grads()
+                loss = learned_loss(a, sg.criterion, st, batch) if learned else _ce(sg.criterion, st.random_out, batch)
+            loss.backward()
+        self.cur.wait_stream(sg.stream)
+        self.st = None
+        return loss.detach()

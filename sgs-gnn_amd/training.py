@@ -155,8 +155,7 @@ def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edg
         if sync is None:
             sync = model._sgs_gradsync = GradSync(model.parameters())
     graphs = None
-    if (getattr(args, "sgs_hipgraph", False) and mode == 'learned' and sync is None and not noise and trace is None
-            and _fused_ce_ok(criterion)):
+    if getattr(args, "sgs_hipgraph", False) and mode == 'learned' and not noise and trace is None and _fused_ce_ok(criterion):
         from .stepgraph import StepGraphs               # opt-in: replay captured HIP graphs of each partition's step
         graphs = StepGraphs.attach(model, pipeline, args, criterion, q, use_checkpoint)
 
@@ -183,25 +182,18 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
 
         if mode == 'learned':
             batch = batch.to(device)
-            if graphs is not None:
-                # opt-in HIP-graph replay of the step's device work (stepgraph.py); same segments as below
-                loss, learned_won = graphs.step(batch, epoch)
-                if learned_won is not None:
-                    r = (args.t_init - args.t_min) / max_epoch
-                    temperature = max(args.t_min, args.t_init - epoch * r)
-                    if learned_won:
-                        condtional_update += 1
-                        optimizer_edge_prob.step()
-                optimizer_gnn.step()
-            elif batch.edge_index.shape[1] > q:
-                st = sampled_forward(pipeline, args, model, batch, q, use_checkpoint, noise)
+            # `h` (stepgraph.py, opt-in): the same segments replayed from captured HIP graphs instead of launched one by one
+            h = graphs.forward(batch) if graphs is not None else None
+            sampled = h.sampled if h is not None else batch.edge_index.shape[1] > q
+            if sampled:
+                st = sampled_forward(pipeline, args, model, batch, q, use_checkpoint, noise) if h is None else None
                 temperature = max(args.t_min, args.t_init - epoch * ((args.t_init - args.t_min) / max_epoch))   # returned, never used by the sampler
 
                 update_edge_mlp = True
                 counts = None
                 any_learned = False
                 if args.conditional:
-                    cbuf = st.cbuf
+                    cbuf = st.cbuf if h is None else h.cbuf
                     if sync is not None:            # N > 1: does ANY rank's gate choose "learned"? (device-side, no extra sync)
                         cbuf[4:5] = sync.any_learned((cbuf[0:1] > cbuf[2:3]).to(torch.int32))
                     counts = cbuf.tolist()                                         # the step's one host read-back
@@ -211,20 +203,26 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
                     update_edge_mlp = counts[0][0] > counts[1][0]
 
                 if sync is not None and not args.conditional:
-                    sync.any_learned(torch.ones(1, dtype=torch.int32, device=st.learned_out.device))   # keep the collective in lock-step
+                    sync.any_learned(torch.ones(1, dtype=torch.int32, device=batch.x.device))   # keep the collective in lock-step
                 if update_edge_mlp:
                     condtional_update += 1
-                    loss = learned_loss(args, criterion, st, batch)
-                    loss.backward()
+                    if h is None:
+                        loss = learned_loss(args, criterion, st, batch)
+                        loss.backward()
+                    else:
+                        loss = h.backward(True)
                     if sync is not None:
                         sync.sync()
                     optimizer_edge_prob.step()
                     optimizer_gnn.step()
                 else:
-                    loss = _ce(criterion, st.random_out, batch)
-                    loss.backward()
+                    if h is None:
+                        loss = _ce(criterion, st.random_out, batch)
+                        loss.backward()
+                    else:
+                        loss = h.backward(False)
                     if sync is not None:
-                        sync.sync()
+                        sync.sync(all_random=not any_learned)
                         if any_learned:
                             optimizer_edge_prob.step()      # another rank's gate chose "learned"
                     optimizer_gnn.step()
@@ -235,15 +233,19 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
                                  random_out=None if st.random_out is None else st.random_out.detach(), counts=counts,
                                  update_edge_mlp=update_edge_mlp, loss=loss.detach())
             else:
-                out = model(batch, batch.edge_index)
-                loss = _ce(criterion, out, batch)
-                loss.backward()
+                if h is None:
+                    out = model(batch, batch.edge_index)
+                    loss = _ce(criterion, out, batch)
+                    loss.backward()
+                else:
+                    loss = h.backward(None)
                 if sync is not None:
                     # every rank is in lock-step on the partition stream, so ranks whose partition is small
                     # (no sampling, no gate) still join the flag all-reduce and the gradient all-reduce
-                    flag = sync.any_learned(torch.zeros(1, dtype=torch.int32, device=out.device))
-                    sync.sync()
-                    if int(flag.item()) > 0:
+                    flag = sync.any_learned(torch.zeros(1, dtype=torch.int32, device=batch.x.device))
+                    some_learned = int(flag.item()) > 0
+                    sync.sync(all_random=not some_learned)
+                    if some_learned:
                         optimizer_edge_prob.step()
                 optimizer_gnn.step()
 

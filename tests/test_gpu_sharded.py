@@ -113,7 +113,7 @@ def test_sharded_draw_and_forward_are_rank_count_invariant():
             torch.testing.assert_close(pt["fwd"]["out"], base["out"], rtol=1e-4, atol=1e-5)
 
 
-def _dp_worker(rank, world, port, q_out):
+def _dp_worker(rank, world, port, q_out, hipgraph=False):
     import sys
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -134,7 +134,7 @@ def _dp_worker(rank, world, port, q_out):
         batches = [S.synthetic_graph(300, e, 12, 5, seed=10 * rank + i, train_frac=0.5, device=DEV) for i, e in enumerate(sizes)]
         args = argparse.Namespace(device=DEV, mode="learned", pipeline="hybrid", conditional=True, sparse_edge_mlp=True, t_init=0.7,
                                   t_min=0.5, degree_bias_coef=0.3, reg1=True, reg2=True, regularizer1_coef=1.0,
-                                  consist_reg_coef=0.5, hybrid_checkpoint=False)
+                                  consist_reg_coef=0.5, hybrid_checkpoint=False, sgs_hipgraph=hipgraph)
         with contextlib.redirect_stdout(io.StringIO()):
             for ep in range(4):
                 ret = S.train(args, ep, 4, m, opt_gnn, opt_edge, opt_all, torch.nn.CrossEntropyLoss(), batches, q=1000)
@@ -143,13 +143,16 @@ def _dp_worker(rank, world, port, q_out):
         dist.destroy_process_group()
 
 
-def test_data_parallel_train_keeps_replicas_identical():
+@pytest.mark.parametrize("hipgraph", [False, True])
+def test_data_parallel_train_keeps_replicas_identical(hipgraph):
     """N > 1 on the partition stream: per-rank batches, one flat gradient all-reduce per step, the scorer's
-    optimiser steps on every rank iff any rank's gate chose 'learned' -> replicas remain bit-identical."""
+    optimiser steps on every rank iff any rank's gate chose 'learned' -> replicas remain bit-identical.
+    hipgraph=True: the same with each rank replaying its partitions' steps from captured HIP graphs
+    (epoch 0 eager, epoch 1 capture, epochs 2-3 replay); the collectives stay between the replays."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, hipgraph)) for r in range(2)]
     for p in procs:
         p.start()
     got = {}
