@@ -42,11 +42,14 @@ def make_args(device):
         hybrid_checkpoint=True, drop_rate=0.3, lr=1e-3)
 
 
-def build_model(S, device):
+def build_model(S, device, fused=True):
+    """Same two Adam optimisers over the same (overlapping) parameter sets as main.py:100,122; `fused` selects torch's
+    single-kernel, capturable Adam (identical update rule) so that a replayed step can include its optimiser steps."""
     torch.manual_seed(42)
     m = S.GNNModel(NFEAT, HID, NCLS, dropout_prob=0.3, edge_mlp_type="GCN").to(device)
-    opt_gnn = torch.optim.Adam([p for n, p in m.named_parameters() if "gcn" in n], lr=1e-3)             # main.py:100
-    opt_edge = torch.optim.Adam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-3)  # main.py:122
+    kw = dict(fused=True, capturable=True) if fused else {}
+    opt_gnn = torch.optim.Adam([p for n, p in m.named_parameters() if "gcn" in n], lr=1e-3, **kw)             # main.py:100
+    opt_edge = torch.optim.Adam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-3, **kw)  # main.py:122
     opt_all = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4)                               # main.py:123
     return m, opt_gnn, opt_edge, opt_all
 
@@ -142,6 +145,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--pool", type=int, default=12, help="distinct partition batches kept resident per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused-adam", type=int, default=1, help="1 (default): torch.optim.Adam(fused=True, capturable=True); 0: torch's default foreach Adam")
     ap.add_argument("--score-variant", type=int, default=-1, help="scorer forward kernel for the timed steps (benchmarking A/B; -1 = library default)")
     ap.add_argument("--hipgraph", type=int, default=1, help="1 (default): replay each partition's step from captured HIP graphs "
                     "(stepgraph.py; every pool partition is visited twice -- eager, capture -- before the W warm-up steps); 0: eager launches")
@@ -165,7 +169,7 @@ def main():
     if a.score_variant >= 0:
         S._lib.lib().sgs_edge_score_set_variant(a.score_variant)
     S.fix_seeds(42 + rank)
-    model, opt_gnn, opt_edge, opt_all = build_model(S, device)
+    model, opt_gnn, opt_edge, opt_all = build_model(S, device, fused=bool(a.fused_adam))
     crit = torch.nn.CrossEntropyLoss()
     args = make_args(device)
 
@@ -227,7 +231,8 @@ def main():
                                    "(52% above q), q=100000, hybrid pipeline, EdgeProbGCN scorer, conditional gate, reg1+reg2, "
                                    "dropout 0.3, Adam x2", "pool": a.pool, "partitions_above_q": sum(1 for b in timed if b.edge_index.shape[1] > Q),
                        "parallelism": f"dp{world} (partition-sharded, 1 flat gradient all-reduce/step)" if world > 1 else "single",
-                       "hipgraph_replay": bool(getattr(args, "sgs_hipgraph", False))},
+                       "hipgraph_replay": bool(getattr(args, "sgs_hipgraph", False)),
+                       "adam": "fused+capturable" if a.fused_adam else "foreach"},
             "mean_loss": round(ret[0], 5), "conditional_updates": ret[2], "total_updates": ret[3],
             "roofline": roof,
         }

@@ -40,6 +40,21 @@ class _Captured:
                  "keep")
 
 
+def _capturable(opt) -> bool:
+    return all(bool(g.get("capturable", False)) for g in opt.param_groups)
+
+
+def _opt_signature(optimizers):
+    """Hyper-parameters a captured optimiser step bakes in (python scalars become kernel arguments)."""
+    if optimizers is None:
+        return None
+    sig = []
+    for o in optimizers:
+        for g in o.param_groups:
+            sig.append((id(o), tuple(sorted((k, v) for k, v in g.items() if isinstance(v, (int, float, bool, tuple, type(None)))))))
+    return tuple(sig)
+
+
 def _batch_key(batch):
     return (batch.x.data_ptr(), batch.edge_index.data_ptr(), batch.y.data_ptr(), batch.train_mask.data_ptr(),
             batch.prob.data_ptr() if getattr(batch, "prob", None) is not None else 0, batch.edge_index.shape[1],
@@ -49,8 +64,9 @@ def _batch_key(batch):
 class StepGraphs:
     """Per-model registry of captured partition steps."""
 
-    def __init__(self, model, pipeline, args, criterion, q, use_checkpoint):
+    def __init__(self, model, pipeline, args, criterion, q, use_checkpoint, optimizers=None):
         self.model = model
+        self.optimizers = optimizers      # (optimizer_edge_prob, optimizer_gnn) when their steps are captured too
         self.pipeline = pipeline
         self.args = args
         self.criterion = criterion
@@ -69,16 +85,24 @@ class StepGraphs:
         a = self.args
         return (self.pipeline, bool(a.conditional), bool(a.sparse_edge_mlp), a.reg1 == True, a.reg2 == True,   # noqa: E712
                 float(a.regularizer1_coef), float(a.consist_reg_coef), float(a.degree_bias_coef), int(self.q),
-                bool(self.use_checkpoint), tuple(p.data_ptr() for p in self.params))
+                bool(self.use_checkpoint), tuple(p.data_ptr() for p in self.params), _opt_signature(self.optimizers))
 
     @classmethod
-    def attach(cls, model, pipeline, args, criterion, q, use_checkpoint):
+    def attach(cls, model, pipeline, args, criterion, q, use_checkpoint, optimizers=None):
+        """`optimizers` = (optimizer_edge_prob, optimizer_gnn): when both are built with `capturable=True` (and the
+        run is single-process) their steps are recorded at the end of the backward graphs, so a replayed step
+        needs no eager launch at all; otherwise the trainer steps them eagerly after each replay."""
+        if optimizers is not None and not all(_capturable(o) for o in optimizers):
+            optimizers = None
         sg = getattr(model, "_sgs_stepgraphs", None)
-        fresh = cls(model, pipeline, args, criterion, q, use_checkpoint) if sg is None else None
+        fresh = cls(model, pipeline, args, criterion, q, use_checkpoint, optimizers) if sg is None else None
         if sg is not None:
             sg.args, sg.criterion = args, criterion
-            if (sg.pipeline, sg.q, sg.use_checkpoint) != (pipeline, q, use_checkpoint) or sg._config_key() != sg.cfg:
-                fresh = cls(model, pipeline, args, criterion, q, use_checkpoint)     # settings changed: drop old captures
+            old_opts = sg.optimizers
+            sg.optimizers = optimizers
+            if ((sg.pipeline, sg.q, sg.use_checkpoint) != (pipeline, q, use_checkpoint) or sg._config_key() != sg.cfg
+                    or (old_opts is None) != (optimizers is None)):
+                fresh = cls(model, pipeline, args, criterion, q, use_checkpoint, optimizers)   # settings changed: drop old captures
         if fresh is not None:
             sg = model._sgs_stepgraphs = fresh
         ops.set_rng_epoch_buffer(sg.epoch_word)
@@ -129,6 +153,8 @@ class StepGraphs:
                 out = self.model(batch, batch.edge_index)
                 c.loss = _ce(self.criterion, out, batch)
                 c.loss.backward()
+                if self.optimizers is not None:
+                    self.optimizers[1].step()                      # optimizer_gnn (training_hybrid.py:161)
             c.grads = self._grads()
             c.loss = c.loss.detach()
             self._clear_grads()
@@ -148,6 +174,9 @@ class StepGraphs:
         with torch.cuda.graph(c.g2l, stream=self.stream, **({"pool": pool} if pool is not None else {})):
             loss_l = learned_loss(a, self.criterion, st, batch)
             loss_l.backward(retain_graph=st.random_out is not None)
+            if self.optimizers is not None:
+                self.optimizers[0].step()                          # optimizer_edge_prob, then optimizer_gnn (:136-137)
+                self.optimizers[1].step()
         c.grads_l = self._grads()
         c.loss_l = loss_l.detach()
         self._clear_grads()
@@ -157,6 +186,8 @@ class StepGraphs:
             with torch.cuda.graph(c.g2r, stream=self.stream, **({"pool": pool} if pool is not None else {})):
                 loss_r = _ce(self.criterion, st.random_out, batch)
                 loss_r.backward()
+                if self.optimizers is not None:
+                    self.optimizers[1].step()                      # optimizer_gnn only (:141)
             c.grads_r = self._grads()
             c.loss_r = loss_r.detach()
             self._clear_grads()
@@ -184,19 +215,28 @@ class StepGraphs:
         """Single-process convenience: forward, gate read-back, backward.  Returns (loss, learned_won | None)."""
         h = self.forward(batch)
         if not h.sampled:
-            return h.backward(None), None
+            loss = h.backward(None)
+            if self.optimizers is not None and not h.opt_in_graph:
+                self.optimizers[1].step()
+            return loss, None
         won = True
         if h.cbuf is not None:
             cnt = h.cbuf.tolist()                      # the step's one host read-back (gate)
             won = cnt[0] > cnt[2]
-        return h.backward(won), won
+        loss = h.backward(won)
+        if self.optimizers is not None and not h.opt_in_graph:
+            if won:
+                self.optimizers[0].step()
+            self.optimizers[1].step()
+        return loss, won
 
 
 class _ReplayHandle:
-    __slots__ = ("sg", "c", "sampled", "cbuf")
+    __slots__ = ("sg", "c", "sampled", "cbuf", "opt_in_graph")
 
     def __init__(self, sg, c):
         self.sg, self.c, self.sampled, self.cbuf = sg, c, c.sampled, c.cbuf
+        self.opt_in_graph = sg.optimizers is not None      # the backward graphs end with the optimiser steps
 
     def backward(self, learned):
         c, sg = self.c, self.sg
@@ -214,11 +254,12 @@ class _ReplayHandle:
 
 class _EagerHandle:
     """First visit of a partition: the same segments launched eagerly on the capture stream (warm-up)."""
-    __slots__ = ("sg", "batch", "sampled", "cbuf", "st", "cur")
+    __slots__ = ("sg", "batch", "sampled", "cbuf", "st", "cur", "opt_in_graph")
 
     def __init__(self, sg, batch):
         from .training import sampled_forward
         self.sg, self.batch = sg, batch
+        self.opt_in_graph = False
         self.sampled = batch.edge_index.shape[1] > sg.q
         self.cbuf, self.st = None, None
         self.cur = torch.cuda.current_stream()

@@ -157,7 +157,8 @@ def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edg
     graphs = None
     if getattr(args, "sgs_hipgraph", False) and mode == 'learned' and not noise and trace is None and _fused_ce_ok(criterion):
         from .stepgraph import StepGraphs               # opt-in: replay captured HIP graphs of each partition's step
-        graphs = StepGraphs.attach(model, pipeline, args, criterion, q, use_checkpoint)
+        graphs = StepGraphs.attach(model, pipeline, args, criterion, q, use_checkpoint,
+                                   optimizers=(optimizer_edge_prob, optimizer_gnn) if sync is None else None)
 
     try:
         return _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, optimizer,
@@ -184,6 +185,7 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
             batch = batch.to(device)
             # `h` (stepgraph.py, opt-in): the same segments replayed from captured HIP graphs instead of launched one by one
             h = graphs.forward(batch) if graphs is not None else None
+            eager_opt = h is None or not h.opt_in_graph       # capturable optimisers are stepped inside the backward graph
             sampled = h.sampled if h is not None else batch.edge_index.shape[1] > q
             if sampled:
                 st = sampled_forward(pipeline, args, model, batch, q, use_checkpoint, noise) if h is None else None
@@ -213,8 +215,9 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
                         loss = h.backward(True)
                     if sync is not None:
                         sync.sync()
-                    optimizer_edge_prob.step()
-                    optimizer_gnn.step()
+                    if eager_opt:
+                        optimizer_edge_prob.step()
+                        optimizer_gnn.step()
                 else:
                     if h is None:
                         loss = _ce(criterion, st.random_out, batch)
@@ -225,7 +228,8 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
                         sync.sync(all_random=not any_learned)
                         if any_learned:
                             optimizer_edge_prob.step()      # another rank's gate chose "learned"
-                    optimizer_gnn.step()
+                    if eager_opt:
+                        optimizer_gnn.step()
 
                 if trace is not None:
                     trace.update(rsei=st.rsei, edge_probs_full=st.edge_probs_full.detach(), sample=st.smp,
@@ -247,7 +251,8 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
                     sync.sync(all_random=not some_learned)
                     if some_learned:
                         optimizer_edge_prob.step()
-                optimizer_gnn.step()
+                if eager_opt:
+                    optimizer_gnn.step()
 
         elif mode == 'random':
             batch = batch.to(device)

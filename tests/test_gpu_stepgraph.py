@@ -21,12 +21,13 @@ def _args(**kw):
     return a
 
 
-def _setup(S, p_drop, seed=3):
+def _setup(S, p_drop, seed=3, capturable=False):
     torch.manual_seed(seed)
     S.fix_seeds(seed)
     m = S.GNNModel(24, 32, 5, dropout_prob=p_drop, edge_mlp_type="GCN").to(DEV)
-    og = torch.optim.Adam([p for n, p in m.named_parameters() if "gcn" in n], lr=1e-2)
-    oe = torch.optim.Adam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-2)
+    kw = dict(capturable=True, fused=True) if capturable else {}
+    og = torch.optim.Adam([p for n, p in m.named_parameters() if "gcn" in n], lr=1e-2, **kw)
+    oe = torch.optim.Adam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-2, **kw)
     return m, og, oe
 
 
@@ -34,13 +35,15 @@ def _batches(S, sizes, n=120, seed=11):
     return [S.synthetic_graph(n, E, 24, 5, seed=seed + i, device=DEV) for i, E in enumerate(sizes)]
 
 
-def test_unsampled_partitions_replay_equals_eager_bitwise():
+@pytest.mark.parametrize("capturable", [False, True])
+def test_unsampled_partitions_replay_equals_eager_bitwise(capturable):
+    """capturable=True: the optimiser steps are recorded at the end of the backward graphs (no eager launch per step)."""
     import sgs_gnn_amd as S
     crit = torch.nn.CrossEntropyLoss()
     bs = _batches(S, [900, 1500, 700])
     q = 5000                                           # every partition below q: no draws, dropout 0 -> deterministic
-    m1, og1, oe1 = _setup(S, 0.0)
-    m2, og2, oe2 = _setup(S, 0.0)
+    m1, og1, oe1 = _setup(S, 0.0, capturable=capturable)
+    m2, og2, oe2 = _setup(S, 0.0, capturable=capturable)
     m2.load_state_dict(copy.deepcopy(m1.state_dict()))
     r1, r2 = [], []
     for ep in range(4):                                # epoch 0 eager warm-up, 1 capture, 2-3 replay
@@ -50,6 +53,7 @@ def test_unsampled_partitions_replay_equals_eager_bitwise():
     for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert torch.equal(p1, p2), n1
     assert len(m2._sgs_stepgraphs.table) == 3
+    assert (m2._sgs_stepgraphs.optimizers is not None) == capturable
     # the RNG epoch word is registered only while a graph-mode train() runs
     assert S.ops._rng_epoch is None
 
@@ -149,12 +153,13 @@ def test_sampled_replay_matches_eager_recomputation_from_its_own_draws(pipeline)
         sg.release()
 
 
-def test_graph_mode_training_with_dropout_runs_and_learns():
+@pytest.mark.parametrize("capturable", [False, True])
+def test_graph_mode_training_with_dropout_runs_and_learns(capturable):
     import sgs_gnn_amd as S
     crit = torch.nn.CrossEntropyLoss()
     bs = _batches(S, [5000, 900, 4000], n=150)
     q = 1000
-    m, og, oe = _setup(S, 0.3)
+    m, og, oe = _setup(S, 0.3, capturable=capturable)
     before = {n: p.detach().clone() for n, p in m.named_parameters()}
 
     def eval_ce():
