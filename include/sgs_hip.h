@@ -293,6 +293,10 @@ int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, i
  * micro-F1 of utils.calculate_f1 == correct[0] / correct[1]; the gate compares two such counts. */
 int sgs_masked_correct(const float* logits, int64_t N, int64_t C, const int64_t* y, const uint8_t* train_mask,
                        int32_t* correct, sgs_stream_t stream);
+/* The F1 gate's two counts (learned vs random logits, training_hybrid.py:92-101) in one launch:
+ * correct4 = {#correct_a, #train, #correct_b, #train}; correct4 must be ZERO on entry (it is accumulated into). */
+int sgs_masked_correct_pair(const float* logits_a, const float* logits_b, int64_t N, int64_t C, const int64_t* y,
+                            const uint8_t* train_mask, int32_t* correct4, sgs_stream_t stream);
 
 /* criterion(out[train_mask], y[train_mask]) for criterion = nn.CrossEntropyLoss() (main.py:125;
  * training_hybrid.py:105,139,145): loss[0] = mean over train rows of (logsumexp - logit[y]).

@@ -132,13 +132,13 @@ __global__ void __launch_bounds__(kT) fill_rows_lds(const int64_t* __restrict__ 
 // The atomic fill leaves each row's edge ids in arrival order; sorting them (unique ints) makes
 // the CSR -- and every floating-point sum over a row -- deterministic.
 // Rows of <= 64 entries: one wave, bitonic network through lane shuffles.
-__global__ void __launch_bounds__(kT) sort_rows_wave(const int* __restrict__ in_ptr, const int* __restrict__ out_ptr, int64_t N,
+__device__ __forceinline__ void sort_rows_wave_body(int64_t block, const int* __restrict__ in_ptr, const int* __restrict__ out_ptr, int64_t N,
                                                     const int* __restrict__ tmp_in, const int* __restrict__ tmp_out,
                                                     const int64_t* __restrict__ ei, int64_t n_edges, int* __restrict__ in_eid,
                                                     int* __restrict__ in_src, int* __restrict__ out_eid,
                                                     int* __restrict__ out_dst) {
     const int lane = threadIdx.x & 63;
-    const int64_t r = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
+    const int64_t r = (block * kT + threadIdx.x) >> 6;
     if (r >= 2 * N) return;
     const bool out = r >= N;
     const int64_t row = out ? r - N : r;
@@ -164,13 +164,11 @@ __global__ void __launch_bounds__(kT) sort_rows_wave(const int* __restrict__ in_
 
 // Rows of > 64 entries: one block per row; bitonic sort in LDS up to kMaxLdsRow entries,
 // rank-by-counting straight from L2 beyond that (hub rows).
-__global__ void __launch_bounds__(kT) sort_rows_block(const int* __restrict__ in_ptr, const int* __restrict__ out_ptr, int64_t N,
+__device__ __forceinline__ void sort_rows_block_body(int64_t r, int* a, const int* __restrict__ in_ptr, const int* __restrict__ out_ptr, int64_t N,
                                                      const int* __restrict__ tmp_in, const int* __restrict__ tmp_out,
                                                      const int64_t* __restrict__ ei, int64_t n_edges, int* __restrict__ in_eid,
                                                      int* __restrict__ in_src, int* __restrict__ out_eid,
                                                      int* __restrict__ out_dst) {
-    __shared__ int a[kMaxLdsRow];
-    const int64_t r = blockIdx.x;
     const bool out = r >= N;
     const int64_t row = out ? r - N : r;
     const int* ptr = out ? out_ptr : in_ptr;
@@ -211,6 +209,20 @@ __global__ void __launch_bounds__(kT) sort_rows_block(const int* __restrict__ in
             col_o[rank] = static_cast<int>(colsrc[v]);
         }
     }
+}
+
+// One launch for both row classes: the first `n_wave_blocks` workgroups sort the short rows (one wave each), the
+// remaining 2N workgroups the long ones (one workgroup each; short rows return at once).
+__global__ void __launch_bounds__(kT) sort_rows(int64_t n_wave_blocks, const int* __restrict__ in_ptr, const int* __restrict__ out_ptr, int64_t N,
+                                               const int* __restrict__ tmp_in, const int* __restrict__ tmp_out,
+                                               const int64_t* __restrict__ ei, int64_t n_edges, int* __restrict__ in_eid,
+                                               int* __restrict__ in_src, int* __restrict__ out_eid, int* __restrict__ out_dst) {
+    __shared__ int a[kMaxLdsRow];
+    if (static_cast<int64_t>(blockIdx.x) < n_wave_blocks)
+        sort_rows_wave_body(blockIdx.x, in_ptr, out_ptr, N, tmp_in, tmp_out, ei, n_edges, in_eid, in_src, out_eid, out_dst);
+    else
+        sort_rows_block_body(static_cast<int64_t>(blockIdx.x) - n_wave_blocks, a, in_ptr, out_ptr, N, tmp_in, tmp_out, ei, n_edges, in_eid,
+                             in_src, out_eid, out_dst);
 }
 
 // ---------------------------------------------------------------- gcn_norm forward
@@ -676,7 +688,7 @@ extern "C" {
 size_t sgs_graph_build_workspace_bytes(int64_t n_edges, int64_t N) {
     if (n_edges < 0) n_edges = 0;
     if (N < 0) N = 0;
-    return 4 * carve_bytes(N + 1, 4) + 2 * carve_bytes(n_edges + 1, 4) + 256;
+    return 4 * carve_bytes(N + 1, 4) + 2 * carve_bytes(n_edges + 1, 4) + 512;
 }
 
 int sgs_graph_build(const int64_t* edge_index, int64_t n_edges, int64_t N, int32_t* in_ptr, int32_t* in_src,
@@ -708,6 +720,8 @@ int sgs_graph_build(const int64_t* edge_index, int64_t n_edges, int64_t N, int32
             hipLaunchKernelGGL(count_degrees, dim3(cdiv(n_edges, kT)), dim3(kT), 0, stream, edge_index, n_edges, cnt_in, cnt_out,
                                loop_eid);
     }
+    // (a "last workgroup scans" variant of the count kernel was tried and is slower on MI355X: the device-scope fences it
+    //  needs write back / invalidate the per-XCD L2s)
     hipLaunchKernelGGL(scan_counts, dim3(2), dim3(1024), 0, stream, cnt_in, cnt_out, N, in_ptr, out_ptr, cur_in, cur_out);
     if (n_edges > 0) {
         if (small_n)
@@ -716,10 +730,9 @@ int sgs_graph_build(const int64_t* edge_index, int64_t n_edges, int64_t N, int32
         else
             hipLaunchKernelGGL(fill_rows, dim3(cdiv(n_edges, kT)), dim3(kT), 0, stream, edge_index, n_edges, cur_in, cur_out,
                                tmp_in, tmp_out);
-        hipLaunchKernelGGL(sort_rows_wave, dim3(cdiv(2 * N * 64, kT)), dim3(kT), 0, stream, in_ptr, out_ptr, N, tmp_in,
-                           tmp_out, edge_index, n_edges, in_eid, in_src, out_eid, out_dst);
-        hipLaunchKernelGGL(sort_rows_block, dim3(2 * N), dim3(kT), 0, stream, in_ptr, out_ptr, N, tmp_in, tmp_out, edge_index,
-                           n_edges, in_eid, in_src, out_eid, out_dst);
+        const int64_t n_wave_blocks = cdiv(2 * N * 64, kT);
+        hipLaunchKernelGGL(sort_rows, dim3(static_cast<unsigned>(n_wave_blocks + 2 * N)), dim3(kT), 0, stream, n_wave_blocks, in_ptr, out_ptr, N,
+                           tmp_in, tmp_out, edge_index, n_edges, in_eid, in_src, out_eid, out_dst);
     }
     SGS_LAUNCH_OK();
     return SGS_OK;

@@ -37,6 +37,37 @@ __global__ void __launch_bounds__(kT) masked_correct(const float* __restrict__ l
     }
 }
 
+// The gate's two counts in one launch: waves [0, N) score logits_a into correct[0:2], waves [N, 2N) logits_b into
+// correct[2:4].  `correct` must be zero on entry (the caller's allocation clears it: one fill for both).
+__global__ void __launch_bounds__(kT) masked_correct_pair(const float* __restrict__ logits_a, const float* __restrict__ logits_b, int64_t N,
+                                                         int64_t C, const int64_t* __restrict__ y, const uint8_t* __restrict__ mask,
+                                                         int* __restrict__ correct) {
+    const int lane = threadIdx.x & 63;
+    int64_t i = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
+    if (i >= 2 * N) return;
+    const bool second = i >= N;
+    if (second) i -= N;
+    if (!mask[i]) return;
+    const float* __restrict__ logits = second ? logits_b : logits_a;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int64_t c = lane; c < C; c += 64) {
+        const float v = logits[i * C + c];
+        if (v > best || (v == best && static_cast<int>(c) < bi) || bi == 0x7fffffff) { best = v; bi = static_cast<int>(c); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        int* out = correct + (second ? 2 : 0);
+        atomicAdd(&out[1], 1);
+        if (static_cast<int64_t>(bi) == y[i]) atomicAdd(&out[0], 1);
+    }
+}
+
 // ---------------------------------------------------------------- masked cross entropy
 // rowloss[i] = lse_i - logit_i[y_i] on train rows (0 elsewhere); row_lse kept for backward.
 __global__ void __launch_bounds__(kT) ce_rows(const float* __restrict__ logits, int64_t N, int64_t C, const int64_t* __restrict__ y,
@@ -224,6 +255,17 @@ int sgs_masked_correct(const float* logits, int64_t N, int64_t C, const int64_t*
     if (N == 0) return SGS_OK;
     SGS_REQUIRE(logits && y && train_mask, SGS_EINVAL, "sgs_masked_correct: null pointer");
     hipLaunchKernelGGL(masked_correct, dim3(cdiv(N * 64, kT)), dim3(kT), 0, stream, logits, N, C, y, train_mask, correct);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_masked_correct_pair(const float* logits_a, const float* logits_b, int64_t N, int64_t C, const int64_t* y,
+                            const uint8_t* train_mask, int32_t* correct4, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && C > 0 && correct4, SGS_EINVAL, "sgs_masked_correct_pair: bad arguments");
+    if (N == 0) return SGS_OK;
+    SGS_REQUIRE(logits_a && logits_b && y && train_mask, SGS_EINVAL, "sgs_masked_correct_pair: null pointer");
+    hipLaunchKernelGGL(masked_correct_pair, dim3(cdiv(2 * N * 64, kT)), dim3(kT), 0, stream, logits_a, logits_b, N, C, y, train_mask, correct4);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

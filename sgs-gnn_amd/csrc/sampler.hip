@@ -154,8 +154,10 @@ __global__ void __launch_bounds__(kThreads) hist_next(const uint32_t* __restrict
 }
 
 // One block: locate the digit bin holding the k_rem-th largest key of the current prefix.
-__global__ void __launch_bounds__(kThreads) select_digit(uint32_t* __restrict__ hist, int shift, int first,
-                                                        uint32_t q, SelectState* __restrict__ st) {
+__device__ __forceinline__ uint32_t load_coherent(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ void select_digit_body(uint32_t* __restrict__ hist, int shift, int first, uint32_t q, SelectState* __restrict__ st) {
     __shared__ uint32_t tsum[kThreads];
     __shared__ uint32_t found_bin, found_above;
     constexpr int per = kBins / kThreads;  // 8 bins per thread, descending order
@@ -165,7 +167,7 @@ __global__ void __launch_bounds__(kThreads) select_digit(uint32_t* __restrict__ 
 #pragma unroll
     for (int j = 0; j < per; ++j) {
         const int bin = kBins - 1 - (threadIdx.x * per + j);
-        loc[j] = hist[bin];
+        loc[j] = load_coherent(hist + bin);
         s += loc[j];
     }
     tsum[threadIdx.x] = s;
@@ -198,6 +200,11 @@ __global__ void __launch_bounds__(kThreads) select_digit(uint32_t* __restrict__ 
     }
     // clear the histogram for the next pass
     for (int i = threadIdx.x; i < kBins; i += kThreads) hist[i] = 0;
+    __syncthreads();
+}
+__global__ void __launch_bounds__(kThreads) select_digit(uint32_t* __restrict__ hist, int shift, int first,
+                                                        uint32_t q, SelectState* __restrict__ st) {
+    select_digit_body(hist, shift, first, q, st);
 }
 
 // ---------------------------------------------------------------- counting + scan + compaction
@@ -240,7 +247,7 @@ __global__ void __launch_bounds__(kThreads) count_blocks(const uint32_t* __restr
 }
 
 // One block: exclusive scan of the per-block (gt, eq) counts, in place.
-__global__ void __launch_bounds__(kThreads) scan_blocks(uint2* __restrict__ cnt, int64_t nblk) {
+__device__ void scan_blocks_body(uint2* __restrict__ cnt, int64_t nblk) {
     __shared__ uint32_t sg[kThreads], se[kThreads];
     const int64_t per = (nblk + kThreads - 1) / kThreads;
     const int64_t lo = static_cast<int64_t>(threadIdx.x) * per;
@@ -263,13 +270,15 @@ __global__ void __launch_bounds__(kThreads) scan_blocks(uint2* __restrict__ cnt,
         rg += c.x; re += c.y;
     }
 }
+__global__ void __launch_bounds__(kThreads) scan_blocks(uint2* __restrict__ cnt, int64_t nblk) { scan_blocks_body(cnt, nblk); }
 
-__global__ void __launch_bounds__(kThreads) compact(const uint32_t* __restrict__ keys, int64_t E, int64_t q, int64_t ties_override,
-                                                   int64_t eid_offset, const SelectState* __restrict__ st, const uint2* __restrict__ cnt,
-                                                   const float* __restrict__ p, const int64_t* __restrict__ edge_index,
-                                                   uint8_t* __restrict__ mask, int mask_aligned,
-                                                   int64_t* __restrict__ sampled_eid, int64_t* __restrict__ sei,
-                                                   float* __restrict__ sampled_p) {
+// blk_gt / blk_eq: number of keys > T / == T in all chunks before this workgroup's
+__device__ __forceinline__ void compact_body(uint32_t blk_gt, uint32_t blk_eq, const uint32_t* __restrict__ keys, int64_t E, int64_t q,
+                                             int64_t ties_override, int64_t eid_offset, const SelectState* __restrict__ st,
+                                             const float* __restrict__ p, const int64_t* __restrict__ edge_index,
+                                             uint8_t* __restrict__ mask, int mask_aligned,
+                                             int64_t* __restrict__ sampled_eid, int64_t* __restrict__ sei,
+                                             float* __restrict__ sampled_p) {
     __shared__ uint32_t wg[kThreads / 64], we[kThreads / 64];
     const uint32_t T = st->prefix, k_rem = ties_override >= 0 ? static_cast<uint32_t>(ties_override) : st->k_rem;
     const int64_t e0 = static_cast<int64_t>(blockIdx.x) * kChunk + static_cast<int64_t>(threadIdx.x) * kItems;
@@ -292,7 +301,7 @@ __global__ void __launch_bounds__(kThreads) compact(const uint32_t* __restrict__
     }
     if (lane == 63) { wg[wid] = ig; we[wid] = ie; }
     __syncthreads();
-    uint32_t bg = cnt[blockIdx.x].x, be = cnt[blockIdx.x].y;
+    uint32_t bg = blk_gt, be = blk_eq;
     for (int w = 0; w < wid; ++w) { bg += wg[w]; be += we[w]; }
     bg += ig - gt;   // #gt with lower id (global)
     be += ie - eq;   // #eq with lower id (global)
@@ -324,6 +333,260 @@ __global__ void __launch_bounds__(kThreads) compact(const uint32_t* __restrict__
         for (int j = 0; j < kItems; ++j)
             if (e0 + j < E) mask[e0 + j] = static_cast<uint8_t>((mbits >> (8 * j)) & 1u);
     }
+}
+__global__ void __launch_bounds__(kThreads) compact(const uint32_t* __restrict__ keys, int64_t E, int64_t q, int64_t ties_override,
+                                                   int64_t eid_offset, const SelectState* __restrict__ st, const uint2* __restrict__ cnt,
+                                                   const float* __restrict__ p, const int64_t* __restrict__ edge_index,
+                                                   uint8_t* __restrict__ mask, int mask_aligned,
+                                                   int64_t* __restrict__ sampled_eid, int64_t* __restrict__ sei,
+                                                   float* __restrict__ sampled_p) {
+    compact_body(cnt[blockIdx.x].x, cnt[blockIdx.x].y, keys, E, q, ties_override, eid_offset, st, p, edge_index, mask, mask_aligned,
+                 sampled_eid, sei, sampled_p);
+}
+
+// ---------------------------------------------------------------- fused small-E path (partition scale)
+// At partition scale (E <= ~2 M) a draw is launch-latency bound, so sgs_sample_topq runs the same algorithm in
+// 6 (learned) / 7 (prior) launches instead of 13 / 15.  The one-workgroup steps between the passes (final reductions,
+// digit selection, block scan) are RECOMPUTED BY EVERY WORKGROUP of the next pass from the complete per-chunk partials /
+// histograms / counts the previous launch left in memory -- a few KB of L2 reads per workgroup, the same arithmetic in
+// the same order (bit-identical Z, max, threshold), no inter-workgroup synchronisation.  (A "last workgroup done"
+// variant with tickets was measured slower on MI355X: the device-scope fences write back / invalidate the per-XCD L2s.)
+constexpr int kSmallBlocks = 1024;     // small path when E <= 1024 chunks (2 M candidate edges)
+
+struct SelPart { uint32_t prefix, k_rem; };
+
+template <int MODE>   // 1: max, otherwise sum (fixed tree, as reduce_final); result in every thread
+__device__ __forceinline__ float final_reduce_all(const float* __restrict__ part, int64_t n, float* red) {
+    float acc = (MODE == 1) ? -INFINITY : 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += kThreads) {
+        const float v = part[i];
+        if (MODE == 1) acc = fmaxf(acc, v);
+        else acc += v;
+    }
+    if (MODE == 1) return block_max(acc, red);
+    const float r = block_sum(acc, red);
+    __shared__ float bc;
+    if (threadIdx.x == 0) bc = r;
+    __syncthreads();
+    const float out = bc;
+    __syncthreads();
+    return out;
+}
+
+// select_digit's search without its side effects: (bin, #keys in higher bins) of the k-th largest key; every thread
+// gets the result.  `hist` is complete (previous launch).
+__device__ __forceinline__ uint2 select_digit_local(const uint32_t* __restrict__ hist, uint32_t k) {
+    __shared__ uint32_t tsum[kThreads];
+    __shared__ uint32_t found_bin, found_above;
+    constexpr int per = kBins / kThreads;
+    uint32_t loc[per];
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < per; ++j) {
+        loc[j] = hist[kBins - 1 - (threadIdx.x * per + j)];
+        s += loc[j];
+    }
+    tsum[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < kThreads; off <<= 1) {
+        uint32_t v = (threadIdx.x >= off) ? tsum[threadIdx.x - off] : 0u;
+        __syncthreads();
+        tsum[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const uint32_t before = tsum[threadIdx.x] - s;
+    if (before < k && before + s >= k) {
+        uint32_t run = before;
+#pragma unroll
+        for (int j = 0; j < per; ++j) {
+            if (run < k && run + loc[j] >= k) {
+                found_bin = kBins - 1 - (threadIdx.x * per + j);
+                found_above = run;
+            }
+            run += loc[j];
+        }
+    }
+    __syncthreads();
+    const uint2 r = make_uint2(found_bin, found_above);
+    __syncthreads();
+    return r;
+}
+
+// first kernel of a draw: per-chunk partial (sum for LEARNED, max for PRIOR) + clears the three digit histograms
+template <int MODE>
+__global__ void __launch_bounds__(kThreads) small_reduce_first(const float* __restrict__ p, int64_t E, float* __restrict__ part,
+                                                              uint32_t* __restrict__ hist3) {
+    __shared__ float red[kThreads / 64];
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < 3 * kBins; i += gridDim.x * kThreads) hist3[i] = 0;
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * kChunk;
+    float acc = (MODE == 1) ? -INFINITY : 0.f;
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
+        if (e < E) {
+            const float v = p[e];
+            if (MODE == 1) acc = fmaxf(acc, v);
+            else acc += v;
+        }
+    }
+    if (MODE == 1) {
+        const float r = block_max(acc, red);
+        if (threadIdx.x == 0) part[blockIdx.x] = r;
+    } else {
+        const float r = block_sum(acc, red);
+        if (threadIdx.x == 0) part[blockIdx.x] = r;
+    }
+}
+
+// PRIOR only: per-chunk partial of sum(exp(p - max)); the max is re-reduced by every workgroup from part_max
+__global__ void __launch_bounds__(kThreads) small_reduce_sumexp(const float* __restrict__ p, int64_t E, const float* __restrict__ part_max,
+                                                               int64_t nblk, float* __restrict__ part_sum) {
+    __shared__ float red[kThreads / 64];
+    const float mx = final_reduce_all<1>(part_max, nblk, red);
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * kChunk;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
+        if (e < E) acc += expf(p[e] - mx);
+    }
+    const float r = block_sum(acc, red);
+    if (threadIdx.x == 0) part_sum[blockIdx.x] = r;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kThreads) small_keys_hist0(const float* __restrict__ p, const float* __restrict__ prior,
+                                                            const float* __restrict__ noise, uint64_t seed, uint64_t stream_id,
+                                                            const uint64_t* __restrict__ epoch, int64_t E, float one_minus_c, float c,
+                                                            const float* __restrict__ part_sum, const float* __restrict__ part_max,
+                                                            int64_t nblk, float* __restrict__ scal, uint32_t* __restrict__ keys,
+                                                            float* __restrict__ keys_out, uint32_t* __restrict__ hist0) {
+    __shared__ uint32_t lh[kBins];
+    __shared__ float red[kThreads / 64];
+    for (int i = threadIdx.x; i < kBins; i += kThreads) lh[i] = 0;
+    seed = fold_epoch(seed, epoch);
+    const float mx = (MODE == SGS_SAMPLE_PRIOR) ? final_reduce_all<1>(part_max, nblk, red) : 0.f;
+    const float Z = final_reduce_all<0>(part_sum, nblk, red);          // (syncs: lh is cleared for everyone)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { scal[0] = Z; scal[1] = mx; }
+    const float Zeps = (MODE == SGS_SAMPLE_LEARNED) ? __fadd_rn(Z, 1e-12f) : Z;
+    const bool has_prior = prior != nullptr;
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * kChunk;
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
+        if (e < E) {
+            const float s = sample_prob<MODE>(p[e], Zeps, mx, has_prior ? prior[e] : 0.f, has_prior, one_minus_c, c);
+            const float nz = noise ? noise[e] : exp_noise_at(seed, stream_id, static_cast<uint64_t>(e));
+            const float key = __fdiv_rn(s, nz);
+            const uint32_t bits = __float_as_uint(key);
+            keys[e] = bits;
+            if (keys_out) keys_out[e] = key;
+            atomicAdd(&lh[bits >> kShift0], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kBins; i += kThreads) {
+        const uint32_t v = lh[i];
+        if (v) atomicAdd(&hist0[i], v);
+    }
+}
+
+// pass d (1 or 2): every workgroup first finishes digit d-1 from the complete hist_prev (+ the state workgroup 0 of the
+// previous pass published), then histograms digit d of the keys matching the prefix; workgroup 0 publishes the state.
+__global__ void __launch_bounds__(kThreads) small_hist_next(const uint32_t* __restrict__ keys, int64_t E, int shift, uint32_t digit_mask,
+                                                           int prev_shift, int first, uint32_t q, const uint32_t* __restrict__ hist_prev,
+                                                           const SelPart* __restrict__ sel_in, SelPart* __restrict__ sel_out,
+                                                           uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[kBins];
+    for (int i = threadIdx.x; i < kBins; i += kThreads) lh[i] = 0;
+    const uint32_t k = first ? q : sel_in->k_rem;
+    const uint32_t pre = first ? 0u : sel_in->prefix;
+    const uint2 f = select_digit_local(hist_prev, k);                  // (syncs: lh is cleared for everyone)
+    const uint32_t prefix = pre | (f.x << prev_shift);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sel_out->prefix = prefix; sel_out->k_rem = k - f.y; }
+    const uint32_t want = prefix >> prev_shift;
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * kChunk;
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
+        if (e < E) {
+            const uint32_t bits = keys[e];
+            if ((bits >> prev_shift) == want) atomicAdd(&lh[(bits >> shift) & digit_mask], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kBins; i += kThreads) {
+        const uint32_t v = lh[i];
+        if (v) atomicAdd(&hist[i], v);
+    }
+}
+
+// every workgroup finishes the last digit (threshold T, ties to take), counts its chunk; workgroup 0 publishes the final
+// SelectState and the stats
+__global__ void __launch_bounds__(kThreads) small_count(const uint32_t* __restrict__ keys, int64_t E, uint32_t q,
+                                                       const uint32_t* __restrict__ hist2, const SelPart* __restrict__ sel_in,
+                                                       SelectState* __restrict__ st, uint2* __restrict__ cnt, const float* __restrict__ scal,
+                                                       float* __restrict__ stats) {
+    __shared__ int red[2 * (kThreads / 64)];
+    const uint32_t k = sel_in->k_rem;
+    const uint2 f = select_digit_local(hist2, k);
+    const uint32_t T = sel_in->prefix | (f.x << kShift2);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->prefix = T;
+        st->k_rem = k - f.y;
+        st->n_gt = q - (k - f.y);
+        st->pad = 0;
+        if (stats) {
+            stats[0] = scal[0];
+            stats[1] = scal[1];
+            stats[2] = __uint_as_float(T);
+            stats[3] = static_cast<float>(k - f.y);
+        }
+    }
+    const int64_t e0 = static_cast<int64_t>(blockIdx.x) * kChunk + static_cast<int64_t>(threadIdx.x) * kItems;
+    uint32_t kk[kItems];
+    load_keys8(keys, e0, E, kk);
+    int gt = 0, eq = 0;
+#pragma unroll
+    for (int j = 0; j < kItems; ++j) {
+        const bool in = e0 + j < E;
+        gt += (in && kk[j] > T);
+        eq += (in && kk[j] == T);
+    }
+    gt = wave_sum_int_all(gt);
+    eq = wave_sum_int_all(eq);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { red[2 * wid] = gt; red[2 * wid + 1] = eq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int g = 0, q_ = 0;
+        for (int w = 0; w < kThreads / 64; ++w) { g += red[2 * w]; q_ += red[2 * w + 1]; }
+        cnt[blockIdx.x] = make_uint2(static_cast<uint32_t>(g), static_cast<uint32_t>(q_));
+    }
+}
+
+// compaction with the exclusive prefix over the preceding chunks' (gt, eq) counts recomputed by each workgroup
+__global__ void __launch_bounds__(kThreads) small_compact(const uint32_t* __restrict__ keys, int64_t E, int64_t q, const SelectState* __restrict__ st,
+                                                         const uint2* __restrict__ cnt, const float* __restrict__ p,
+                                                         const int64_t* __restrict__ edge_index, uint8_t* __restrict__ mask, int mask_aligned,
+                                                         int64_t* __restrict__ sampled_eid, int64_t* __restrict__ sei,
+                                                         float* __restrict__ sampled_p) {
+    __shared__ int red[2 * (kThreads / 64)];
+    __shared__ uint32_t pre[2];
+    int g = 0, e = 0;
+    for (int i = threadIdx.x; i < static_cast<int>(blockIdx.x); i += kThreads) { g += static_cast<int>(cnt[i].x); e += static_cast<int>(cnt[i].y); }
+    g = wave_sum_int_all(g);
+    e = wave_sum_int_all(e);
+    if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = g; red[2 * (threadIdx.x >> 6) + 1] = e; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int G = 0, Q = 0;
+        for (int w = 0; w < kThreads / 64; ++w) { G += red[2 * w]; Q += red[2 * w + 1]; }
+        pre[0] = static_cast<uint32_t>(G);
+        pre[1] = static_cast<uint32_t>(Q);
+    }
+    __syncthreads();
+    compact_body(pre[0], pre[1], keys, E, q, int64_t(-1), int64_t(0), st, p, edge_index, mask, mask_aligned, sampled_eid, sei, sampled_p);
 }
 
 // counts[0] = #keys > threshold, counts[1] = #keys == threshold in this shard (before the scan).
@@ -494,7 +757,8 @@ size_t sgs_sample_topq_workspace_bytes(int64_t E) {
            + carve_bytes(nblk, 4)       // partial sums
            + carve_bytes(4, 4)          // scalars Z, max
            + carve_bytes(kBins, 4)      // histogram
-           + carve_bytes(1, sizeof(SelectState)) + carve_bytes(nblk, sizeof(uint2)) + 256;
+           + carve_bytes(1, sizeof(SelectState)) + carve_bytes(nblk, sizeof(uint2))
+           + carve_bytes(nblk, 4) + carve_bytes(3 * kBins, 4) + 256 + 256;   // fused small-E path: second partials, per-digit histograms
 }
 
 int sgs_sample_topq(int mode, const float* p, const float* prior, double degree_bias_coef, const float* noise,
@@ -523,10 +787,42 @@ int sgs_sample_topq(int mode, const float* p, const float* prior, double degree_
     SelectState* st = cv.take<SelectState>(1);
     uint2* cnt = cv.take<uint2>(nblk + 1);
 
+    float* part2 = cv.take<float>(nblk + 1);
+    uint32_t* hist3 = cv.take<uint32_t>(3 * kBins);       // fused small-E path: one histogram per digit
+    SelPart* sel = cv.take<SelPart>(2);
+    const dim3 grid(static_cast<unsigned>(nblk)), blk(kThreads);
+    // python: (1 - c) and c are doubles, cast to fp32 when they meet the fp32 tensor
+    const float one_minus_c = static_cast<float>(1.0 - degree_bias_coef);
+    const float c = static_cast<float>(degree_bias_coef);
+    const int mask_aligned = (reinterpret_cast<uintptr_t>(mask) & 7) == 0;
+
+    if (nblk <= kSmallBlocks && q > 0 && q < E) {
+        // fused small-E path: 6 / 7 launches (see "fused small-E path" above); same arithmetic, same results
+        const uint32_t q32 = static_cast<uint32_t>(q);
+        uint32_t *h0 = hist3, *h1 = hist3 + kBins, *h2 = hist3 + 2 * kBins;
+        if (mode == SGS_SAMPLE_LEARNED) {
+            hipLaunchKernelGGL(small_reduce_first<0>, grid, blk, 0, stream, p, E, part, hist3);
+            hipLaunchKernelGGL(small_keys_hist0<SGS_SAMPLE_LEARNED>, grid, blk, 0, stream, p, prior, noise, seed, stream_id, epoch_ptr(), E,
+                               one_minus_c, c, part, static_cast<const float*>(nullptr), nblk, scal, keys, keys_out, h0);
+        } else {
+            hipLaunchKernelGGL(small_reduce_first<1>, grid, blk, 0, stream, p, E, part, hist3);
+            hipLaunchKernelGGL(small_reduce_sumexp, grid, blk, 0, stream, p, E, part, nblk, part2);
+            hipLaunchKernelGGL(small_keys_hist0<SGS_SAMPLE_PRIOR>, grid, blk, 0, stream, p, static_cast<const float*>(nullptr), noise, seed,
+                               stream_id, epoch_ptr(), E, one_minus_c, c, part2, part, nblk, scal, keys, keys_out, h0);
+        }
+        hipLaunchKernelGGL(small_hist_next, grid, blk, 0, stream, keys, E, kShift1, kMask1, kShift0, 1, q32, h0,
+                           static_cast<const SelPart*>(nullptr), sel, h1);
+        hipLaunchKernelGGL(small_hist_next, grid, blk, 0, stream, keys, E, kShift2, kMask2, kShift1, 0, q32, h1, sel, sel + 1, h2);
+        hipLaunchKernelGGL(small_count, grid, blk, 0, stream, keys, E, q32, h2, sel + 1, st, cnt, scal, stats);
+        hipLaunchKernelGGL(small_compact, grid, blk, 0, stream, keys, E, q, st, cnt, p, edge_index, mask, mask_aligned, sampled_eid,
+                           sampled_edge_index, sampled_p);
+        SGS_LAUNCH_OK();
+        return SGS_OK;
+    }
+
     // scal, hist and st are adjacent carvings: one zeroing launch (a kernel, not a memset node: see zero_async)
     if (int rc = zero_async(scal, static_cast<size_t>(reinterpret_cast<char*>(st + 1) - reinterpret_cast<char*>(scal)), stream)) return rc;
 
-    const dim3 grid(static_cast<unsigned>(nblk)), blk(kThreads);
     if (mode == SGS_SAMPLE_LEARNED) {
         hipLaunchKernelGGL(reduce_partial<0>, grid, blk, 0, stream, p, E, scal, part);
         hipLaunchKernelGGL(reduce_final<0>, dim3(1), blk, 0, stream, part, nblk, scal);
@@ -546,9 +842,6 @@ int sgs_sample_topq(int mode, const float* p, const float* prior, double degree_
         return SGS_OK;
     }
 
-    // python: (1 - c) and c are doubles, cast to fp32 when they meet the fp32 tensor
-    const float one_minus_c = static_cast<float>(1.0 - degree_bias_coef);
-    const float c = static_cast<float>(degree_bias_coef);
     if (mode == SGS_SAMPLE_LEARNED)
         hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_LEARNED>, grid, blk, 0, stream, p, prior, noise, seed, stream_id, epoch_ptr(), int64_t(0), E,
                            one_minus_c, c, scal, keys, keys_out, hist);
@@ -562,7 +855,6 @@ int sgs_sample_topq(int mode, const float* p, const float* prior, double degree_
     hipLaunchKernelGGL(select_digit, dim3(1), blk, 0, stream, hist, kShift2, 0, static_cast<uint32_t>(q), st);
     hipLaunchKernelGGL(count_blocks, grid, blk, 0, stream, keys, E, st, cnt);
     hipLaunchKernelGGL(scan_blocks, dim3(1), blk, 0, stream, cnt, nblk);
-    const int mask_aligned = (reinterpret_cast<uintptr_t>(mask) & 7) == 0;
     hipLaunchKernelGGL(compact, grid, blk, 0, stream, keys, E, q, int64_t(-1), int64_t(0), st, cnt, p, edge_index, mask, mask_aligned,
                        sampled_eid, sampled_edge_index, sampled_p);
     if (stats) hipLaunchKernelGGL(write_stats, dim3(1), dim3(1), 0, stream, scal, st, stats);

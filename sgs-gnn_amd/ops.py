@@ -260,9 +260,13 @@ class _GCNNorm(torch.autograd.Function):
 
 
 def gcn_norm(graph: Graph, w=None) -> Norm:
-    """K4.  `w` [n_edges] f32 or None (unit weights)."""
+    """K4.  `w` [n_edges] f32 or None (unit weights).  The unit-weight result depends on the graph alone and is kept on it:
+    the scorer's encoder and the GNN's random forward normalise the same random subgraph (training_hybrid.py:52,93)."""
     if w is None:
-        return _norm_forward(graph, None)
+        nm = getattr(graph, "_norm_unit", None)
+        if nm is None:
+            nm = graph._norm_unit = _norm_forward(graph, None)
+        return nm
     _need_gpu(w)
     w = w.contiguous()
     if w.dtype != torch.float32 or w.numel() != graph.n_edges:
@@ -441,6 +445,20 @@ def masked_correct(logits, y, train_mask, out=None) -> torch.Tensor:
     N, C = logits.shape
     _lib.check(L.sgs_masked_correct(_ptr(logits.contiguous(), torch.float32), N, C, _ptr(y, torch.int64), _ptr(_u8(train_mask)),
                                     _ptr(out), _stream()), "sgs_masked_correct")
+    return out
+
+
+def masked_correct_pair(logits_a, logits_b, y, train_mask, out) -> torch.Tensor:
+    """The gate's two counts in one launch: out[0:4] = (#correct_a, #train, #correct_b, #train); `out` (int32, >= 4 entries)
+    must be zero on entry."""
+    L = _lib.lib()
+    _need_gpu(logits_a, logits_b, y, train_mask, out)
+    N, C = logits_a.shape
+    if logits_b.shape != logits_a.shape:
+        raise RuntimeError("masked_correct_pair: logits shapes differ")
+    _lib.check(L.sgs_masked_correct_pair(_ptr(logits_a.contiguous(), torch.float32), _ptr(logits_b.contiguous(), torch.float32), N, C,
+                                         _ptr(y, torch.int64), _ptr(_u8(train_mask)), _ptr(out, torch.int32), _stream()),
+               "sgs_masked_correct_pair")
     return out
 
 

@@ -99,9 +99,8 @@ def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise
     st.cbuf = None
     if args.conditional:
         st.random_out = model(batch, st.rsei)
-        st.cbuf = torch.empty(5, dtype=torch.int32, device=st.learned_out.device)
-        ops.masked_correct(st.learned_out, batch.y, batch.train_mask, out=st.cbuf[0:2])
-        ops.masked_correct(st.random_out, batch.y, batch.train_mask, out=st.cbuf[2:4])
+        st.cbuf = torch.zeros(5, dtype=torch.int32, device=st.learned_out.device)
+        ops.masked_correct_pair(st.learned_out, st.random_out, batch.y, batch.train_mask, st.cbuf)
     return st
 
 
