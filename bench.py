@@ -43,13 +43,14 @@ def make_args(device):
 
 
 def build_model(S, device, fused=True):
-    """Same two Adam optimisers over the same (overlapping) parameter sets as main.py:100,122; `fused` selects torch's
-    single-kernel, capturable Adam (identical update rule) so that a replayed step can include its optimiser steps."""
+    """Same two Adam optimisers over the same (overlapping) parameter sets as main.py:100,122; `fused` selects
+    sgs_gnn_amd.FusedAdam (one launch per group, torch.optim.Adam's update rule and state layout, capturable) so that a
+    replayed step includes its optimiser steps; 0 = torch.optim.Adam (foreach), stepped eagerly after each replay."""
     torch.manual_seed(42)
     m = S.GNNModel(NFEAT, HID, NCLS, dropout_prob=0.3, edge_mlp_type="GCN").to(device)
-    kw = dict(fused=True, capturable=True) if fused else {}
-    opt_gnn = torch.optim.Adam([p for n, p in m.named_parameters() if "gcn" in n], lr=1e-3, **kw)             # main.py:100
-    opt_edge = torch.optim.Adam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-3, **kw)  # main.py:122
+    Adam = S.FusedAdam if fused else torch.optim.Adam
+    opt_gnn = Adam([p for n, p in m.named_parameters() if "gcn" in n], lr=1e-3)             # main.py:100
+    opt_edge = Adam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-3)  # main.py:122
     opt_all = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4)                               # main.py:123
     return m, opt_gnn, opt_edge, opt_all
 
@@ -145,7 +146,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--pool", type=int, default=12, help="distinct partition batches kept resident per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fused-adam", type=int, default=1, help="1 (default): torch.optim.Adam(fused=True, capturable=True); 0: torch's default foreach Adam")
+    ap.add_argument("--fused-adam", type=int, default=1, help="1 (default): sgs_gnn_amd.FusedAdam (one launch per group, captured with the step); 0: torch.optim.Adam (foreach, eager)")
     ap.add_argument("--score-variant", type=int, default=-1, help="scorer forward kernel for the timed steps (benchmarking A/B; -1 = library default)")
     ap.add_argument("--hipgraph", type=int, default=1, help="1 (default): replay each partition's step from captured HIP graphs "
                     "(stepgraph.py; every pool partition is visited twice -- eager, capture -- before the W warm-up steps); 0: eager launches")
@@ -213,13 +214,17 @@ def main():
         big = max(pool, key=lambda b: b.edge_index.shape[1])
         L = S._lib.lib()
         alts = {}
-        for v, name in ((0, "lds_tiled"), (2, "weight_stationary_persistent")):   # in-process A/B of the scorer forward kernels
+        names = {0: "lds_tiled", 1: "stream_32_edge_wave_tile", 2: "weight_stationary_persistent", 3: "stream_64_edge_wave_tile"}
+        used = a.score_variant if a.score_variant >= 0 else 3           # automatic choice at this E (>= 65 536 edges)
+        for v, name in names.items():                                      # in-process A/B of the scorer forward kernels
+            if v == used:
+                continue
             L.sgs_edge_score_set_variant(v)
             r_ = kernel_roofline(S, model, big, reps=20)
             alts[name] = {"achieved": r_["achieved"], "ms_per_launch": r_["ms_per_launch"]}
-        L.sgs_edge_score_set_variant(1 if a.score_variant < 0 else a.score_variant)
-        roof = kernel_roofline(S, model, big, reps=20)       # the variant used by the timed steps above (default: 1)
-        roof["kernel"] = "edge_score_stream_kernel<8> (sgs_edge_score_fwd, register-streaming variant)"
+        L.sgs_edge_score_set_variant(a.score_variant)
+        roof = kernel_roofline(S, model, big, reps=20)       # the variant used by the timed steps above
+        roof["kernel"] = f"sgs_edge_score_fwd, forward variant {used} ({names[used]})"
         roof["alt_variants"] = alts
         rec = {
             "metric": "sampled edges/sec + training steps/sec, Reddit hybrid 20% sparsity",
@@ -232,7 +237,7 @@ def main():
                                    "dropout 0.3, Adam x2", "pool": a.pool, "partitions_above_q": sum(1 for b in timed if b.edge_index.shape[1] > Q),
                        "parallelism": f"dp{world} (partition-sharded, 1 flat gradient all-reduce/step)" if world > 1 else "single",
                        "hipgraph_replay": bool(getattr(args, "sgs_hipgraph", False)),
-                       "adam": "fused+capturable" if a.fused_adam else "foreach"},
+                       "adam": "sgs_gnn_amd.FusedAdam (in-graph)" if a.fused_adam else "torch.optim.Adam (foreach, eager)"},
             "mean_loss": round(ret[0], 5), "conditional_updates": ret[2], "total_updates": ret[3],
             "roofline": roof,
         }

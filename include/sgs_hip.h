@@ -270,8 +270,9 @@ int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, void* ws, size_
  *   d codes (direct) = reduce(dfeat, dfeat, T = codes, +1, +1);   d U = reduce(dv, dv, NULL, +1, -1).
  * ---------------------------------------------------------------------------------- */
 size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H, int64_t E);   /* E = 0 for the backward core */
-void sgs_edge_score_set_variant(int variant);   /* forward kernel: 0 = LDS-tiled, 1 = register-streaming (default),
-                                                   2 = weight-stationary persistent; benchmarking switch */
+void sgs_edge_score_set_variant(int variant);   /* forward kernel: -1 = automatic (default: 3 when E >= 65 536, else 1),
+                                                  * 0 = LDS-tiled, 1 = register-streaming (32-edge wave tile), 2 = weight-stationary
+                                                  * persistent, 3 = register-streaming with a 64-edge wave tile; all give the same p */
 int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
                        int64_t edge_id_offset, const float* W1, const float* b1, const float* w2, const float* b2,
                        float p_drop, uint64_t seed, uint32_t site, float* p_out, void* ws, size_t ws_bytes,
@@ -361,6 +362,19 @@ int sgs_scatter_by_eid(const float* in_order, const int32_t* eid, int64_t n, flo
 size_t sgs_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N);
 int sgs_gemm_tn(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, void* ws, size_t ws_bytes,
                 sgs_stream_t stream);
+
+/* ----------------------------------------------------------------------------------
+ * Optimiser (training_hybrid.py:22-27, 135-141: two torch.optim.Adam steps per batch).
+ * One launch updates up to sgs_adam_max_tensors() tensors with torch.optim.Adam's rule (coupled weight decay, no amsgrad):
+ *   desc_host [n_tensors][6] int64 in HOST memory, read during the call only (the descriptors travel by value in the
+ *             kernel arguments): {param, grad, exp_avg, exp_avg_sq, numel, step}; the five pointers are DEVICE addresses;
+ *             `step` is that tensor's float counter of completed steps (one per parameter, as torch), read and then
+ *             incremented by the kernel, so the call is capturable into a HIP graph
+ *   ticket    device uint32, zero on first use (the kernel leaves it zero); one per concurrently running call
+ * ---------------------------------------------------------------------------------- */
+int sgs_adam_max_tensors(void);
+int sgs_adam_step(const int64_t* desc_host, int64_t n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int maximize, uint32_t* ticket, sgs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -344,6 +344,11 @@ __global__ void __launch_bounds__(kT, 3) edge_score_stream_kernel(ScoreArgs a, c
             }
         }
     };
+    // (Measured alternative, rejected: unconditional refills of both stages pinned with sched_barrier give exact
+    //  vmcnt(8)/vmcnt(5) waits instead of the vmcnt(0) the conditional refill below forces at its join, but every stage
+    //  then gets only one 16-MFMA group of cover and the kernel drops from 102 to 78 TFLOP/s: with ~13 TB/s of L1->L2
+    //  requests in flight the load latency is well above one group, and the schedule below issues stage 1 in the MIDDLE of
+    //  stage 0's MFMA group, which is what matters.)
     load(0, A0, x0, y0);
 #pragma unroll 1
     for (int j4 = 0; j4 < NJ4; j4 += 2) {
@@ -353,41 +358,59 @@ __global__ void __launch_bounds__(kT, 3) edge_score_stream_kernel(ScoreArgs a, c
         mma(A1, x1, y1);
     }
 
-    // ---- epilogue (same as the tiled kernel): hidden unit hh*H/2 + 32t + (q&3) + 8(q>>2) + 4kh
-    const int Hrt = a.H;
+    // ---- epilogue: hidden unit hh*H/2 + 32t + (q&3) + 8(q>>2) + 4kh.  Sixteen (tile, group) steps per wave, each
+    // needing the endpoint rows of U (two gathers) + b1 + w2.  The loads of step i+1 are issued before step i is
+    // processed (two register stages; the A/B operand stages are dead by now), so a wave
+    // exposes ONE gather latency here instead of sixteen; letting the compiler hoist freely blows the register budget.
     const uint32_t rkey = dropout_row_key(fold_epoch(a.seed, a.epoch), a.site, static_cast<uint64_t>(a.row_offset + eg_id));
-    const float* Us = a.U + static_cast<int64_t>(s) * H;
-    const float* Ud = a.U + static_cast<int64_t>(d) * H;
+    const float* Us = a.U + static_cast<int64_t>(s) * H + hh * (H / 2) + 4 * kh;
+    const float* Ud = a.U + static_cast<int64_t>(d) * H + hh * (H / 2) + 4 * kh;
+    const float* b1p = a.b1 + hh * (H / 2) + 4 * kh;
+    const float* w2p = a.w2 + hh * (H / 2) + 4 * kh;
+    struct Epi { float4 us, ud, bb, ww; };
+    auto eload = [&](int i, Epi& L) {                // i = 4 t + g -> offset 32 t + 8 g = 8 i
+        L.us = *reinterpret_cast<const float4*>(Us + 8 * i);
+        L.ud = *reinterpret_cast<const float4*>(Ud + 8 * i);
+        L.bb = *reinterpret_cast<const float4*>(b1p + 8 * i);
+        L.ww = *reinterpret_cast<const float4*>(w2p + 8 * i);
+    };
     float z = 0.f;
+    auto estep = [&](int i, const Epi& L) {
+        const int t = i >> 2, g = i & 3;
+        const int hb = hh * (H / 2) + 8 * i + 4 * kh;
+        const float u4[4] = {L.us.x - L.ud.x, L.us.y - L.ud.y, L.us.z - L.ud.z, L.us.w - L.ud.w};
+        const float b4[4] = {L.bb.x, L.bb.y, L.bb.z, L.bb.w};
+        const float w4[4] = {L.ww.x, L.ww.y, L.ww.z, L.ww.w};
+        uint32_t bits[2] = {0u, 0u};
+        if (a.use_drop) {
+            bits[0] = dropout_pair_bits(rkey, static_cast<uint32_t>(hb >> 1));
+            bits[1] = dropout_pair_bits(rkey, static_cast<uint32_t>((hb >> 1) + 1));
+        }
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int hb = hh * (H / 2) + 32 * t + 8 * g + 4 * kh;
-            if (hb < Hrt) {      // always true; the runtime bound keeps hipcc from hoisting all 64 float4 loads at once
-                const float4 us = *reinterpret_cast<const float4*>(Us + hb);
-                const float4 ud = *reinterpret_cast<const float4*>(Ud + hb);
-                const float4 bb = *reinterpret_cast<const float4*>(a.b1 + hb);
-                const float4 ww = *reinterpret_cast<const float4*>(a.w2 + hb);
-                const float u4[4] = {us.x - ud.x, us.y - ud.y, us.z - ud.z, us.w - ud.w};
-                const float b4[4] = {bb.x, bb.y, bb.z, bb.w};
-                const float w4[4] = {ww.x, ww.y, ww.z, ww.w};
-                uint32_t bits[2] = {0u, 0u};
-                if (a.use_drop) {
-                    bits[0] = dropout_pair_bits(rkey, static_cast<uint32_t>(hb >> 1));
-                    bits[1] = dropout_pair_bits(rkey, static_cast<uint32_t>((hb >> 1) + 1));
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = (acc[t][4 * g + j] + u4[j]) + b4[j];
-                    float m = v > 0.f ? 1.f : 0.f;
-                    if (a.use_drop) {
-                        const uint32_t draw = (j & 1) ? (bits[j >> 1] >> 16) : (bits[j >> 1] & 0xFFFFu);
-                        m = draw >= a.drop_thresh ? m * a.drop_scale : 0.f;
-                    }
-                    z = fmaf(w4[j], v * m, z);
-                }
+        for (int j = 0; j < 4; ++j) {
+            const float v = (acc[t][4 * g + j] + u4[j]) + b4[j];
+            float m = v > 0.f ? 1.f : 0.f;
+            if (a.use_drop) {
+                const uint32_t draw = (j & 1) ? (bits[j >> 1] >> 16) : (bits[j >> 1] & 0xFFFFu);
+                m = draw >= a.drop_thresh ? m * a.drop_scale : 0.f;
             }
+            z = fmaf(w4[j], v * m, z);
+        }
+    };
+    const int Hrt = a.H;
+    Epi L0, L1;
+    eload(0, L0);
+#pragma unroll
+    for (int i = 0; i < 4 * NTW; i += 2) {
+        // the (always true) run-time bounds keep every step in its own basic block: the next step's loads are issued
+        // at its head and cannot be hoisted further, which bounds the live registers to two stages
+        if (8 * i < Hrt) {
+            eload(i + 1, L1);
+            estep(i, L0);
+        }
+        if (8 * i + 8 < Hrt) {
+            if (i + 2 < 4 * NTW) eload(i + 2, L0);
+            estep(i + 1, L1);
         }
     }
     z += __shfl_xor(z, 32, 64);
@@ -396,6 +419,151 @@ __global__ void __launch_bounds__(kT, 3) edge_score_stream_kernel(ScoreArgs a, c
     if (live && hh == 0 && kh == 0) {
         const float zz = (zpart[0][el] + zpart[1][el]) + a.b2[0];
         a.p_out[r] = 1.0f / (1.0f + expf(-zz));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward variant D ("stream, 64-edge wave tile").  tools/ceilings/ceilings.hip isolates the main loop of variant B and
+// shows that it -- not the gathers, the dropout hash, the epilogue or the tail -- caps the kernel: with a 32-edge x
+// 128-hidden wave tile every 16 MFMAs need 6 operand loads, and the L1/L2 request stream (~13 TB/s) inflates the load
+// latency beyond what three waves per SIMD can cover (109 TFLOP/s for the bare loop).  Doubling the edges per wave
+// (64 x 128: 8 accumulators, 2 waves per SIMD) reuses every A value twice: 8 loads per 32 MFMAs, 130 TFLOP/s for the
+// bare loop.  Workgroup = 128 edges x all H hidden units: wave = (edge pair-group, hidden half).
+constexpr int kBM2 = 128;
+template <int NT>
+__global__ void __launch_bounds__(kT, 2) edge_score_stream64_kernel(ScoreArgs a, const float* __restrict__ Wp, const float* __restrict__ Ceo) {
+    constexpr int H = 32 * NT;
+    constexpr int NTW = NT / 2;
+    constexpr int NJ4 = H / 8;
+    __shared__ float zpart[2][kBM2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ep = wave & 1, hh = wave >> 1;
+    const int kh = lane >> 5, l31 = lane & 31;
+    const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kBM2;
+    int el[2], s[2], d[2];
+    int64_t eg_id[2];
+    bool live[2];
+    const float4 *xp[2], *yp[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        el[g] = 64 * ep + 32 * g + l31;
+        const int64_t r = row0 + el[g];
+        live[g] = r < a.n;
+        s[g] = 0; d[g] = 0; eg_id[g] = 0;
+        if (live[g]) {
+            eg_id[g] = a.active ? a.active[r] : r;
+            s[g] = static_cast<int>(a.src[eg_id[g]]);
+            d[g] = static_cast<int>(a.dst[eg_id[g]]);
+        }
+        xp[g] = reinterpret_cast<const float4*>(Ceo + static_cast<int64_t>(s[g]) * H + kh * (H / 2));
+        yp[g] = reinterpret_cast<const float4*>(Ceo + static_cast<int64_t>(d[g]) * H + kh * (H / 2));
+    }
+    const float4* wp = reinterpret_cast<const float4*>(Wp) + (static_cast<int64_t>(hh) * NTW * NJ4) * 64 + lane;
+
+    f32x16 acc[2][NTW];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[g][t][q] = 0.f;
+
+    float4 A0[NTW], A1[NTW], x0[2], y0[2], x1[2], y1[2];
+    auto load = [&](int j4, float4 (&A)[NTW], float4 (&x)[2], float4 (&y)[2]) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) A[t] = wp[(static_cast<int64_t>(t) * NJ4 + j4) * 64];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) { x[g] = xp[g][j4]; y[g] = yp[g][j4]; }
+    };
+    auto mma = [&](const float4 (&A)[NTW], const float4 (&x)[2], const float4 (&y)[2]) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float bx = jj == 0 ? x[g].x : jj == 1 ? x[g].y : jj == 2 ? x[g].z : x[g].w;
+                const float by = jj == 0 ? y[g].x : jj == 1 ? y[g].y : jj == 2 ? y[g].z : y[g].w;
+                const float b = bx * by;
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    const float av = jj == 0 ? A[t].x : jj == 1 ? A[t].y : jj == 2 ? A[t].z : A[t].w;
+                    acc[g][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[g][t], 0, 0, 0);
+                }
+            }
+        }
+    };
+    load(0, A0, x0, y0);
+#pragma unroll 1
+    for (int j4 = 0; j4 < NJ4; j4 += 2) {
+        load(j4 + 1, A1, x1, y1);                    // NJ4 is even (H % 16 == 0)
+        mma(A0, x0, y0);
+        if (j4 + 2 < NJ4) load(j4 + 2, A0, x0, y0);
+        mma(A1, x1, y1);
+    }
+
+    // ---- epilogue (as variant B, once per edge group): hidden unit hh*H/2 + 8 i + (j) + 4 kh for step i = 4 t + g4
+    const int Hrt = a.H;
+    const float* b1p = a.b1 + hh * (H / 2) + 4 * kh;
+    const float* w2p = a.w2 + hh * (H / 2) + 4 * kh;
+    struct Epi { float4 us, ud, bb, ww; };
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const uint32_t rkey = dropout_row_key(fold_epoch(a.seed, a.epoch), a.site, static_cast<uint64_t>(a.row_offset + eg_id[g]));
+        const float* Us = a.U + static_cast<int64_t>(s[g]) * H + hh * (H / 2) + 4 * kh;
+        const float* Ud = a.U + static_cast<int64_t>(d[g]) * H + hh * (H / 2) + 4 * kh;
+        auto eload = [&](int i, Epi& L) {
+            L.us = *reinterpret_cast<const float4*>(Us + 8 * i);
+            L.ud = *reinterpret_cast<const float4*>(Ud + 8 * i);
+            L.bb = *reinterpret_cast<const float4*>(b1p + 8 * i);
+            L.ww = *reinterpret_cast<const float4*>(w2p + 8 * i);
+        };
+        float z = 0.f;
+        auto estep = [&](int i, const Epi& L) {
+            const int t = i >> 2, g4 = i & 3;
+            const int hb = hh * (H / 2) + 8 * i + 4 * kh;
+            const float u4[4] = {L.us.x - L.ud.x, L.us.y - L.ud.y, L.us.z - L.ud.z, L.us.w - L.ud.w};
+            const float b4[4] = {L.bb.x, L.bb.y, L.bb.z, L.bb.w};
+            const float w4[4] = {L.ww.x, L.ww.y, L.ww.z, L.ww.w};
+            uint32_t bits[2] = {0u, 0u};
+            if (a.use_drop) {
+                bits[0] = dropout_pair_bits(rkey, static_cast<uint32_t>(hb >> 1));
+                bits[1] = dropout_pair_bits(rkey, static_cast<uint32_t>((hb >> 1) + 1));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = (acc[g][t][4 * g4 + j] + u4[j]) + b4[j];
+                float m = v > 0.f ? 1.f : 0.f;
+                if (a.use_drop) {
+                    const uint32_t draw = (j & 1) ? (bits[j >> 1] >> 16) : (bits[j >> 1] & 0xFFFFu);
+                    m = draw >= a.drop_thresh ? m * a.drop_scale : 0.f;
+                }
+                z = fmaf(w4[j], v * m, z);
+            }
+        };
+        Epi L0, L1;
+        eload(0, L0);
+#pragma unroll
+        for (int i = 0; i < 4 * NTW; i += 2) {
+            if (8 * i < Hrt) {                       // always true: one basic block per step bounds the live registers
+                eload(i + 1, L1);
+                estep(i, L0);
+            }
+            if (8 * i + 8 < Hrt) {
+                if (i + 2 < 4 * NTW) eload(i + 2, L0);
+                estep(i + 1, L1);
+            }
+        }
+        z += __shfl_xor(z, 32, 64);
+        if (kh == 0) zpart[hh][el[g]] = z;
+    }
+    __syncthreads();
+    if (hh == 0 && kh == 0) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (live[g]) {
+                const float zz = (zpart[0][el[g]] + zpart[1][el[g]]) + a.b2[0];
+                a.p_out[row0 + el[g]] = 1.0f / (1.0f + expf(-zz));
+            }
+        }
     }
 }
 
@@ -683,7 +851,7 @@ size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H, int64_t E) {
 // 0 = LDS-tiled kernel, 1 = register-streaming kernel, 2 = weight-stationary persistent kernel (forward, H % 64 == 0).
 // A/B switch for benchmarks.  Measured (MI355X, E = 351 194, H = 256, same process): 0 -> 95, 1 -> 100.7, 2 -> 99.5 TFLOP/s;
 // whole-step throughput is equal within noise, so the fastest kernel is the default.
-static int g_score_variant = 1;
+static int g_score_variant = -1;   // -1: automatic (3 when the launch fills the chip with 128-edge workgroups, else 1)
 void sgs_edge_score_set_variant(int v) { g_score_variant = v; }
 
 int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
@@ -703,7 +871,9 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
     a.WaT = WaT; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.drop_scale = 1.0f / (1.0f - p_drop); a.drop_thresh = dropout_thresh(p_drop); a.seed = seed; a.epoch = epoch_ptr(); a.site = site;
     a.use_drop = p_drop > 0.f; a.p_out = p_out;
-    if (g_score_variant == 2 && H % 64 == 0 && N > 0) {
+    int variant = g_score_variant;
+    if (variant < 0) variant = (cdiv(E, kBM2) >= 512) ? 3 : 1;          // 512 = 2 resident workgroups x 256 CUs
+    if (variant == 2 && H % 64 == 0 && N > 0) {
         float* zpart = cv.take<float>(2 * static_cast<size_t>(E));
         unsigned int* ctr = cv.take<unsigned int>(64);
         if (int rc = zero_async(ctr, 256, stream)) return rc;
@@ -732,7 +902,17 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
         SGS_LAUNCH_OK();
         return SGS_OK;
     }
-    if (g_score_variant == 1 && H % 64 == 0 && N > 0) {
+    if (variant == 3 && H % 64 == 0 && N > 0) {
+        hipLaunchKernelGGL(pack_w1a_stream, dim3(cdiv(H * H, kT)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);
+        hipLaunchKernelGGL(pack_codes_eo, dim3(cdiv(N * H, kT)), dim3(kT), 0, stream, codes, N, static_cast<int>(H), Ceo);
+        const dim3 grid(static_cast<unsigned>(cdiv(E, kBM2))), blk(kT);
+        if (H == 256)      hipLaunchKernelGGL((edge_score_stream64_kernel<8>), grid, blk, 0, stream, a, WaT, Ceo);
+        else if (H == 128) hipLaunchKernelGGL((edge_score_stream64_kernel<4>), grid, blk, 0, stream, a, WaT, Ceo);
+        else               hipLaunchKernelGGL((edge_score_stream64_kernel<2>), grid, blk, 0, stream, a, WaT, Ceo);
+        SGS_LAUNCH_OK();
+        return SGS_OK;
+    }
+    if (variant == 1 && H % 64 == 0 && N > 0) {
         hipLaunchKernelGGL(pack_w1a_stream, dim3(cdiv(H * H, kT)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);
         hipLaunchKernelGGL(pack_codes_eo, dim3(cdiv(N * H, kT)), dim3(kT), 0, stream, codes, N, static_cast<int>(H), Ceo);
         const dim3 grid(static_cast<unsigned>(cdiv(E, kBM))), blk(kT);

@@ -679,6 +679,7 @@ class _GCNLayer(torch.autograd.Function):
         ctx.has_bias, ctx.has_handle = bias is not None, handle is not None
         ctx.save_for_backward(x, W, xl, Y if act != ACT_NONE else None)
         ctx.mark_non_differentiable(xl)
+        ctx.set_materialize_grads(False)        # no zero-filled [N, D] gradient for the (never differentiated) xl output
         return Y, xl
 
     @staticmethod

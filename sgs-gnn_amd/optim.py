@@ -1,0 +1,69 @@
+"""Adam as one launch per parameter group (csrc/optim.hip): a drop-in for the two `torch.optim.Adam` objects the
+reference builds (main.py:100, 122) with the same update rule, the same `state_dict` layout (`step`, `exp_avg`,
+`exp_avg_sq` per parameter) and `capturable=True`, so `train(..., args.sgs_hipgraph=True)` records its steps inside
+the backward graphs.
+
+    optimizer_gnn = sgs_gnn_amd.FusedAdam([p for n, p in model.named_parameters() if 'gcn' in n], lr=args.lr)
+
+Parameters whose `.grad` is None are skipped, exactly as torch does (that matters: the two optimisers overlap on
+`edge_prob_mlp.gcn*`, and the random-wins branch leaves the scorer without gradients)."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib, ops
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, maximize=False):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("FusedAdam: invalid hyper-parameters")
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, maximize=maximize, capturable=True, amsgrad=False,
+                        foreach=None, fused=None, differentiable=False)
+        super().__init__(params, defaults)
+        self._tickets = {}
+
+    def _init_state(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _lib.lib()
+        kmax = L.sgs_adam_max_tensors()
+        stream = ops._stream()
+        for gi, group in enumerate(self.param_groups):
+            plist = [p for p in group["params"] if p.grad is not None]
+            if not plist:
+                continue
+            b1, b2 = group["betas"]
+            for lo in range(0, len(plist), kmax):
+                part = plist[lo:lo + kmax]
+                words = []
+                for p in part:
+                    g = p.grad
+                    if (p.dtype != torch.float32 or g.dtype != torch.float32 or not p.is_cuda or g.is_sparse or not p.is_contiguous()
+                            or not g.is_contiguous()):
+                        raise RuntimeError("FusedAdam: parameters and gradients must be dense, contiguous float32 HIP tensors")
+                    st = self._init_state(p)
+                    words += [p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
+                              st["step"].data_ptr()]
+                key = (gi, lo)
+                tk = self._tickets.get(key)
+                if tk is None:
+                    tk = self._tickets[key] = torch.zeros(1, dtype=torch.int32, device=part[0].device)
+                arr = (ctypes.c_int64 * len(words))(*words)
+                _lib.check(L.sgs_adam_step(arr, len(part), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                           float(group["weight_decay"]), int(bool(group["maximize"])), tk.data_ptr(), stream),
+                           "sgs_adam_step")
+        return loss

@@ -89,10 +89,10 @@ def test_scorer_tail_and_probability_range(ops):
     assert float((pd.cpu() - po).abs().max()) < 2e-6
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("N,H,E,p", [(300, 64, 5001, 0.0), (1013, 256, 30011, 0.3), (200, 128, 77, 0.3)])
 def test_all_forward_variants_match_oracle(ops, variant, N, H, E, p):
-    """LDS-tiled (0), register-streaming (1, default) and weight-stationary persistent (2) forward kernels."""
+    """LDS-tiled (0), register-streaming 32-edge (1) / 64-edge (3) wave tiles and weight-stationary persistent (2) forward kernels."""
     import sgs_gnn_amd as S
     L = S._lib.lib()
     codes, ei, W1, b1, W2, b2, g = _case(N, H, E, 31 + H)
@@ -104,5 +104,5 @@ def test_all_forward_variants_match_oracle(ops, variant, N, H, E, p):
         pd = ops.edge_score(codes.to(DEV), W1.to(DEV), b1.to(DEV), W2.to(DEV), b2.to(DEV), ei.to(DEV), p=p, seed=seed, site=site)
         torch.cuda.synchronize()
     finally:
-        L.sgs_edge_score_set_variant(1)
+        L.sgs_edge_score_set_variant(-1)
     assert float((pd.cpu().double() - po).abs().max()) < 2e-6
