@@ -296,6 +296,28 @@ __global__ void __launch_bounds__(kT) pack_codes_eo(const float* __restrict__ co
     Ceo[n * H + (k & 1) * (H / 2) + (k >> 1)] = codes[i];
 }
 
+// both re-layouts in one launch (the forward is launch-latency sensitive at partition scale): the first n_w workgroups
+// pack W1a, the rest re-lay the codes
+__global__ void __launch_bounds__(kT) pack_stream_operands(const float* __restrict__ W1, int H, float* __restrict__ Wp, int n_w,
+                                                          const float* __restrict__ codes, int64_t N, float* __restrict__ Ceo) {
+    if (static_cast<int>(blockIdx.x) < n_w) {
+        const int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;     // one output float
+        if (i >= static_cast<int64_t>(H) * H) return;
+        const int jj = i & 3, lane = (i >> 2) & 63;
+        const int64_t rest = i >> 8;                  // t * (H/8) + j4
+        const int j4 = static_cast<int>(rest % (H / 8)), t = static_cast<int>(rest / (H / 8));
+        const int kh = lane >> 5, l31 = lane & 31;
+        const int k = 8 * j4 + 2 * jj + kh, h = 32 * t + l31;
+        Wp[i] = W1[static_cast<int64_t>(h) * 2 * H + k];
+    } else {
+        const int64_t i = (static_cast<int64_t>(blockIdx.x) - n_w) * kT + threadIdx.x;
+        if (i >= N * H) return;
+        const int64_t n = i / H;
+        const int k = static_cast<int>(i - n * H);
+        Ceo[n * H + (k & 1) * (H / 2) + (k >> 1)] = codes[i];
+    }
+}
+
 template <int NT>
 __global__ void __launch_bounds__(kT, 3) edge_score_stream_kernel(ScoreArgs a, const float* __restrict__ Wp, const float* __restrict__ Ceo) {
     constexpr int H = 32 * NT;
@@ -877,8 +899,11 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
         float* zpart = cv.take<float>(2 * static_cast<size_t>(E));
         unsigned int* ctr = cv.take<unsigned int>(64);
         if (int rc = zero_async(ctr, 256, stream)) return rc;
-        hipLaunchKernelGGL(pack_w1a_stream, dim3(cdiv(H * H, kT)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);
-        hipLaunchKernelGGL(pack_codes_eo, dim3(cdiv(N * H, kT)), dim3(kT), 0, stream, codes, N, static_cast<int>(H), Ceo);
+        {
+            const int n_w = static_cast<int>(cdiv(H * H, kT));
+            hipLaunchKernelGGL(pack_stream_operands, dim3(static_cast<unsigned>(n_w + cdiv(N * H, kT))), dim3(kT), 0, stream, W1,
+                               static_cast<int>(H), WaT, n_w, codes, N, Ceo);
+        }
         constexpr int TH = 768;                                             // 12 waves = 3 per SIMD (168-register budget; 16 waves spill)
         const size_t sm = static_cast<size_t>(H / 2) * H * 4;             // this half of W1a, packed
         const int64_t n_tiles = cdiv(E, 32);
@@ -903,8 +928,11 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
         return SGS_OK;
     }
     if (variant == 3 && H % 64 == 0 && N > 0) {
-        hipLaunchKernelGGL(pack_w1a_stream, dim3(cdiv(H * H, kT)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);
-        hipLaunchKernelGGL(pack_codes_eo, dim3(cdiv(N * H, kT)), dim3(kT), 0, stream, codes, N, static_cast<int>(H), Ceo);
+        {
+            const int n_w = static_cast<int>(cdiv(H * H, kT));
+            hipLaunchKernelGGL(pack_stream_operands, dim3(static_cast<unsigned>(n_w + cdiv(N * H, kT))), dim3(kT), 0, stream, W1,
+                               static_cast<int>(H), WaT, n_w, codes, N, Ceo);
+        }
         const dim3 grid(static_cast<unsigned>(cdiv(E, kBM2))), blk(kT);
         if (H == 256)      hipLaunchKernelGGL((edge_score_stream64_kernel<8>), grid, blk, 0, stream, a, WaT, Ceo);
         else if (H == 128) hipLaunchKernelGGL((edge_score_stream64_kernel<4>), grid, blk, 0, stream, a, WaT, Ceo);
@@ -913,8 +941,11 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
         return SGS_OK;
     }
     if (variant == 1 && H % 64 == 0 && N > 0) {
-        hipLaunchKernelGGL(pack_w1a_stream, dim3(cdiv(H * H, kT)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);
-        hipLaunchKernelGGL(pack_codes_eo, dim3(cdiv(N * H, kT)), dim3(kT), 0, stream, codes, N, static_cast<int>(H), Ceo);
+        {
+            const int n_w = static_cast<int>(cdiv(H * H, kT));
+            hipLaunchKernelGGL(pack_stream_operands, dim3(static_cast<unsigned>(n_w + cdiv(N * H, kT))), dim3(kT), 0, stream, W1,
+                               static_cast<int>(H), WaT, n_w, codes, N, Ceo);
+        }
         const dim3 grid(static_cast<unsigned>(cdiv(E, kBM))), blk(kT);
         if (H == 256)      hipLaunchKernelGGL((edge_score_stream_kernel<8>), grid, blk, 0, stream, a, WaT, Ceo);
         else if (H == 128) hipLaunchKernelGGL((edge_score_stream_kernel<4>), grid, blk, 0, stream, a, WaT, Ceo);

@@ -616,12 +616,15 @@ __global__ void __launch_bounds__(kT) act_bwd(const float* __restrict__ dY, cons
 // Column sums of a [N, D] matrix (bias / fc2 gradients), two fixed-order stages so the result is
 // deterministic and the first stage fills the chip: block (cx, ry) sums kColRows rows of 64 columns.
 constexpr int kColRows = 256;
-__global__ void __launch_bounds__(kT) colsum_partial(const float* __restrict__ A, int64_t N, int64_t D, float* __restrict__ part) {
+// rows per first-stage workgroup: 256 for tall matrices, down to 32 for partition-sized ones so that the first stage
+// still spreads over the chip (N = 1013: 32 row chunks x D/64 column groups instead of 4 x D/64)
+inline int colsum_rows(int64_t N) { return N >= 16384 ? kColRows : (N >= 4096 ? 128 : 32); }
+__global__ void __launch_bounds__(kT) colsum_partial(const float* __restrict__ A, int64_t N, int64_t D, int rows, float* __restrict__ part) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rgrp = threadIdx.x >> 6;
-    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * kColRows;
-    const int64_t r1 = (r0 + kColRows < N) ? r0 + kColRows : N;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows;
+    const int64_t r1 = (r0 + rows < N) ? r0 + rows : N;
     float acc = 0.f;
     if (c < D)
         for (int64_t r = r0 + rgrp; r < r1; r += 4) acc += A[r * D + c];
@@ -926,7 +929,7 @@ int sgs_act_bwd(const float* dY, const float* Y, int64_t n, int act, float p_dro
 size_t sgs_colsum_workspace_bytes(int64_t N, int64_t D) {
     if (N < 0) N = 0;
     if (D < 0) D = 0;
-    return carve_bytes(static_cast<size_t>(cdiv(N, kColRows) + 1) * D, 4) + 256;
+    return carve_bytes(static_cast<size_t>(cdiv(N, colsum_rows(N)) + 1) * D, 4) + 256;
 }
 
 int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, void* ws, size_t ws_bytes, sgs_stream_t stream_) {
@@ -936,10 +939,11 @@ int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, void* ws, size_
     SGS_REQUIRE(out && (N == 0 || A), SGS_EINVAL, "sgs_colsum: null pointer");
     SGS_REQUIRE(ws && ws_bytes >= sgs_colsum_workspace_bytes(N, D), SGS_EWORKSPACE, "sgs_colsum: workspace too small");
     Carver cv(ws);
-    const int64_t nchunk = cdiv(N, kColRows);
+    const int rows = colsum_rows(N);
+    const int64_t nchunk = cdiv(N, rows);
     float* part = cv.take<float>(static_cast<size_t>(nchunk + 1) * D);
     if (nchunk > 0)
-        hipLaunchKernelGGL(colsum_partial, dim3(cdiv(D, 64), nchunk), dim3(kT), 0, stream, A, N, D, part);
+        hipLaunchKernelGGL(colsum_partial, dim3(cdiv(D, 64), nchunk), dim3(kT), 0, stream, A, N, D, rows, part);
     hipLaunchKernelGGL(colsum_final, dim3(cdiv(D, 64)), dim3(kT), 0, stream, part, nchunk, D, out);
     SGS_LAUNCH_OK();
     return SGS_OK;

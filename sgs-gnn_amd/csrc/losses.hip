@@ -39,32 +39,40 @@ __global__ void __launch_bounds__(kT) masked_correct(const float* __restrict__ l
 
 // The gate's two counts in one launch: waves [0, N) score logits_a into correct[0:2], waves [N, 2N) logits_b into
 // correct[2:4].  `correct` must be zero on entry (the caller's allocation clears it: one fill for both).
-__global__ void __launch_bounds__(kT) masked_correct_pair(const float* __restrict__ logits_a, const float* __restrict__ logits_b, int64_t N,
-                                                         int64_t C, const int64_t* __restrict__ y, const uint8_t* __restrict__ mask,
-                                                         int* __restrict__ correct) {
-    const int lane = threadIdx.x & 63;
-    int64_t i = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
-    if (i >= 2 * N) return;
-    const bool second = i >= N;
-    if (second) i -= N;
-    if (!mask[i]) return;
-    const float* __restrict__ logits = second ? logits_b : logits_a;
-    float best = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int64_t c = lane; c < C; c += 64) {
-        const float v = logits[i * C + c];
-        if (v > best || (v == best && static_cast<int>(c) < bi) || bi == 0x7fffffff) { best = v; bi = static_cast<int>(c); }
-    }
+__global__ void __launch_bounds__(1024) masked_correct_pair(const float* __restrict__ logits_a, const float* __restrict__ logits_b, int64_t N,
+                                                           int64_t C, const int64_t* __restrict__ y, const uint8_t* __restrict__ mask,
+                                                           int* __restrict__ correct) {
+    // 16 waves = 16 rows of ONE of the two logit matrices per workgroup (blockIdx.y selects it): the counts are reduced in LDS
+    // and each workgroup issues two atomics instead of every row issuing two
+    __shared__ int red[2 * 16];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 16 + wid;
+    const float* __restrict__ logits = blockIdx.y ? logits_b : logits_a;
+    int ok = 0, row = 0;
+    if (i < N && mask[i]) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int64_t c = lane; c < C; c += 64) {
+            const float v = logits[i * C + c];
+            if (v > best || (v == best && static_cast<int>(c) < bi) || bi == 0x7fffffff) { best = v; bi = static_cast<int>(c); }
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+        }
+        row = 1;
+        ok = (static_cast<int64_t>(bi) == y[i]) ? 1 : 0;
     }
-    if (lane == 0) {
-        int* out = correct + (second ? 2 : 0);
-        atomicAdd(&out[1], 1);
-        if (static_cast<int64_t>(bi) == y[i]) atomicAdd(&out[0], 1);
+    if (lane == 0) { red[2 * wid] = ok; red[2 * wid + 1] = row; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a_ = 0, b_ = 0;
+        for (int w = 0; w < 16; ++w) { a_ += red[2 * w]; b_ += red[2 * w + 1]; }
+        int* out = correct + (blockIdx.y ? 2 : 0);
+        if (b_) atomicAdd(&out[1], b_);
+        if (a_) atomicAdd(&out[0], a_);
     }
 }
 
@@ -265,7 +273,8 @@ int sgs_masked_correct_pair(const float* logits_a, const float* logits_b, int64_
     SGS_REQUIRE(N >= 0 && C > 0 && correct4, SGS_EINVAL, "sgs_masked_correct_pair: bad arguments");
     if (N == 0) return SGS_OK;
     SGS_REQUIRE(logits_a && logits_b && y && train_mask, SGS_EINVAL, "sgs_masked_correct_pair: null pointer");
-    hipLaunchKernelGGL(masked_correct_pair, dim3(cdiv(2 * N * 64, kT)), dim3(kT), 0, stream, logits_a, logits_b, N, C, y, train_mask, correct4);
+    hipLaunchKernelGGL(masked_correct_pair, dim3(static_cast<unsigned>(cdiv(N, 16)), 2), dim3(1024), 0, stream, logits_a, logits_b, N, C, y, train_mask,
+                       correct4);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

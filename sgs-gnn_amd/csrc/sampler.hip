@@ -454,6 +454,8 @@ __global__ void __launch_bounds__(kThreads) small_reduce_sumexp(const float* __r
     if (threadIdx.x == 0) part_sum[blockIdx.x] = r;
 }
 
+constexpr int kKeyItems = 2;          // the key pass is ALU heavy (Philox + log + 2 divisions per edge): 512-edge workgroups spread a
+                                      // partition over ~3x more workgroups than the 2048-edge chunks of the reduction passes
 template <int MODE>
 __global__ void __launch_bounds__(kThreads) small_keys_hist0(const float* __restrict__ p, const float* __restrict__ prior,
                                                             const float* __restrict__ noise, uint64_t seed, uint64_t stream_id,
@@ -470,9 +472,9 @@ __global__ void __launch_bounds__(kThreads) small_keys_hist0(const float* __rest
     if (blockIdx.x == 0 && threadIdx.x == 0) { scal[0] = Z; scal[1] = mx; }
     const float Zeps = (MODE == SGS_SAMPLE_LEARNED) ? __fadd_rn(Z, 1e-12f) : Z;
     const bool has_prior = prior != nullptr;
-    const int64_t base = static_cast<int64_t>(blockIdx.x) * kChunk;
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * (kThreads * kKeyItems);
 #pragma unroll
-    for (int i = 0; i < kItems; ++i) {
+    for (int i = 0; i < kKeyItems; ++i) {
         const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
         if (e < E) {
             const float s = sample_prob<MODE>(p[e], Zeps, mx, has_prior ? prior[e] : 0.f, has_prior, one_minus_c, c);
@@ -800,14 +802,15 @@ int sgs_sample_topq(int mode, const float* p, const float* prior, double degree_
         // fused small-E path: 6 / 7 launches (see "fused small-E path" above); same arithmetic, same results
         const uint32_t q32 = static_cast<uint32_t>(q);
         uint32_t *h0 = hist3, *h1 = hist3 + kBins, *h2 = hist3 + 2 * kBins;
+        const dim3 kgrid(static_cast<unsigned>(cdiv(E, kThreads * kKeyItems)));
         if (mode == SGS_SAMPLE_LEARNED) {
             hipLaunchKernelGGL(small_reduce_first<0>, grid, blk, 0, stream, p, E, part, hist3);
-            hipLaunchKernelGGL(small_keys_hist0<SGS_SAMPLE_LEARNED>, grid, blk, 0, stream, p, prior, noise, seed, stream_id, epoch_ptr(), E,
+            hipLaunchKernelGGL(small_keys_hist0<SGS_SAMPLE_LEARNED>, kgrid, blk, 0, stream, p, prior, noise, seed, stream_id, epoch_ptr(), E,
                                one_minus_c, c, part, static_cast<const float*>(nullptr), nblk, scal, keys, keys_out, h0);
         } else {
             hipLaunchKernelGGL(small_reduce_first<1>, grid, blk, 0, stream, p, E, part, hist3);
             hipLaunchKernelGGL(small_reduce_sumexp, grid, blk, 0, stream, p, E, part, nblk, part2);
-            hipLaunchKernelGGL(small_keys_hist0<SGS_SAMPLE_PRIOR>, grid, blk, 0, stream, p, static_cast<const float*>(nullptr), noise, seed,
+            hipLaunchKernelGGL(small_keys_hist0<SGS_SAMPLE_PRIOR>, kgrid, blk, 0, stream, p, static_cast<const float*>(nullptr), noise, seed,
                                stream_id, epoch_ptr(), E, one_minus_c, c, part2, part, nblk, scal, keys, keys_out, h0);
         }
         hipLaunchKernelGGL(small_hist_next, grid, blk, 0, stream, keys, E, kShift1, kMask1, kShift0, 1, q32, h0,

@@ -157,6 +157,29 @@ class _STWeights(torch.autograd.Function):
         return gp, None, None, None, None
 
 
+class _SelectSampled(torch.autograd.Function):
+    """probs[eid] with the VALUES the sampler's compaction already gathered (sgs_sample_topq's sampled_p): the forward
+    launches nothing; the backward is index_select's (scatter of the q gradients into zeros [E]; the eids are unique)."""
+
+    @staticmethod
+    def forward(ctx, probs, eid, values):
+        ctx.save_for_backward(eid)
+        ctx.E = probs.numel()
+        return values.view_as(values)
+
+    @staticmethod
+    def backward(ctx, g):
+        (eid,) = ctx.saved_tensors
+        gp = torch.zeros(ctx.E, dtype=g.dtype, device=g.device)
+        gp.index_copy_(0, eid, g.contiguous())
+        return gp, None, None
+
+
+def select_sampled(probs, eid, values):
+    _need_gpu(probs, eid, values)
+    return _SelectSampled.apply(probs, eid, values)
+
+
 def st_weights(p, prior, c, stats, eid):
     _need_gpu(p, prior, stats, eid)
     return _STWeights.apply(p.contiguous(), prior, c, stats, eid)

@@ -25,7 +25,7 @@ def manual_seed(seed: int) -> None:
     set_dropout_seed(seed)
 
 
-def draw_learned(prior, edge_probs, edge_index, q, degree_bias_coef=0.3, istest=False, noise=None) -> ops.SampleResult:
+def draw_learned(prior, edge_probs, edge_index, q, degree_bias_coef=0.3, istest=False, noise=None, want_p=False) -> ops.SampleResult:
     """K2+K3: the learned draw; `edge_probs` is used detached (sampling itself is not differentiable)."""
     E = edge_index.shape[1]
     if edge_probs.numel() != E or (not istest and prior.numel() != E):
@@ -34,7 +34,7 @@ def draw_learned(prior, edge_probs, edge_index, q, degree_bias_coef=0.3, istest=
                            f"({E if istest else prior.numel()}) at non-singleton dimension 0")
     seed, sid = (0, 0) if noise is not None else _NoiseClock.next()
     return ops.sample_topq(ops.SAMPLE_LEARNED, edge_probs.detach().contiguous(), None if istest else prior, degree_bias_coef, q,
-                           edge_index, noise=noise, seed=seed, stream_id=sid, want_p=False)
+                           edge_index, noise=noise, seed=seed, stream_id=sid, want_p=want_p)
 
 
 def draw_prior(prob, edge_index, q, noise=None) -> ops.SampleResult:

@@ -78,6 +78,7 @@ class StepGraphs:
         # warm-up visits and captures share one side stream: autograd stamps every node (AccumulateGrad included)
         # with the stream it was created on, and a capture must not meet nodes from the legacy default stream
         self.stream = torch.cuda.Stream(device=self.device)
+        self.one = torch.ones((), dtype=torch.float32, device=self.device)      # root gradient: saves autograd's ones_like fill per backward
         self.table = {}          # batch key -> _Captured | "seen"
         self.cfg = self._config_key()
 
@@ -152,7 +153,7 @@ class StepGraphs:
                 self.epoch_word.add_(1)
                 out = self.model(batch, batch.edge_index)
                 c.loss = _ce(self.criterion, out, batch)
-                c.loss.backward()
+                c.loss.backward(gradient=self.one)
                 if self.optimizers is not None:
                     self.optimizers[1].step()                      # optimizer_gnn (training_hybrid.py:161)
             c.grads = self._grads()
@@ -173,7 +174,7 @@ class StepGraphs:
         c.g2l = torch.cuda.CUDAGraph()
         with torch.cuda.graph(c.g2l, stream=self.stream, **({"pool": pool} if pool is not None else {})):
             loss_l = learned_loss(a, self.criterion, st, batch)
-            loss_l.backward(retain_graph=st.random_out is not None)
+            loss_l.backward(gradient=self.one, retain_graph=st.random_out is not None)
             if self.optimizers is not None:
                 self.optimizers[0].step()                          # optimizer_edge_prob, then optimizer_gnn (:136-137)
                 self.optimizers[1].step()
@@ -185,7 +186,7 @@ class StepGraphs:
             c.g2r = torch.cuda.CUDAGraph()
             with torch.cuda.graph(c.g2r, stream=self.stream, **({"pool": pool} if pool is not None else {})):
                 loss_r = _ce(self.criterion, st.random_out, batch)
-                loss_r.backward()
+                loss_r.backward(gradient=self.one)
                 if self.optimizers is not None:
                     self.optimizers[1].step()                      # optimizer_gnn only (:141)
             c.grads_r = self._grads()

@@ -79,7 +79,7 @@ def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise
 
     # K2+K3: learned draw on detached probabilities, compacted columns in edge order
     st.smp = smp = draw_learned(batch.prob, st.edge_probs_full, batch.edge_index, q, args.degree_bias_coef,
-                                noise=noise.get("sample"))
+                                noise=noise.get("sample"), want_p=(pipeline == "hybrid"))
     st.sampled_edge_index = smp.edge_index
     graph_s = ops.get_graph(smp.edge_index, N)
 
@@ -87,7 +87,7 @@ def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise
         # edge_probs_full[mask]: gradient reaches only the q sampled entries
         if pass1_active is not None:
             pass1_active.set(smp.eid, graph_s)
-        st.edge_probs_for_loss = st.edge_probs_full.index_select(0, smp.eid)
+        st.edge_probs_for_loss = ops.select_sampled(st.edge_probs_full, smp.eid, smp.p)    # = edge_probs_full[mask], gathered by the draw
     elif pipeline == "straight_through":
         st.edge_probs_for_loss = ops.st_weights(st.edge_probs_full, batch.prob, args.degree_bias_coef, smp.stats, smp.eid)
     else:
