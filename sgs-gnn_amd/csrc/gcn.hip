@@ -633,16 +633,22 @@ __global__ void __launch_bounds__(kT) colsum_partial(const float* __restrict__ A
     if (rgrp == 0 && c < D)
         part[static_cast<int64_t>(blockIdx.y) * D + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ void __launch_bounds__(kT) colsum_final(const float* __restrict__ part, int64_t nchunk, int64_t D, float* __restrict__ out) {
-    __shared__ float red[4][64];
+template <int RG>    // RG row groups of 64 columns per workgroup (RG * 64 threads): 4 for a handful of partials, 16 for tall inputs
+__global__ void __launch_bounds__(RG * 64) colsum_final(const float* __restrict__ part, int64_t nchunk, int64_t D, float* __restrict__ out) {
+    __shared__ float red[RG][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rgrp = threadIdx.x >> 6;
     float acc = 0.f;
     if (c < D)
-        for (int64_t r = rgrp; r < nchunk; r += 4) acc += part[r * D + c];
+        for (int64_t r = rgrp; r < nchunk; r += RG) acc += part[r * D + c];
     red[rgrp][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (rgrp == 0 && c < D) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (rgrp == 0 && c < D) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < RG; g += 4) s += (red[g][threadIdx.x] + red[g + 1][threadIdx.x]) + (red[g + 2][threadIdx.x] + red[g + 3][threadIdx.x]);
+        out[c] = s;
+    }
 }
 
 inline int pick_lpr(int64_t D, int vec) {
@@ -944,7 +950,8 @@ int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, void* ws, size_
     float* part = cv.take<float>(static_cast<size_t>(nchunk + 1) * D);
     if (nchunk > 0)
         hipLaunchKernelGGL(colsum_partial, dim3(cdiv(D, 64), nchunk), dim3(kT), 0, stream, A, N, D, rows, part);
-    hipLaunchKernelGGL(colsum_final, dim3(cdiv(D, 64)), dim3(kT), 0, stream, part, nchunk, D, out);
+    if (nchunk > 64) hipLaunchKernelGGL(colsum_final<16>, dim3(cdiv(D, 64)), dim3(1024), 0, stream, part, nchunk, D, out);
+    else             hipLaunchKernelGGL(colsum_final<4>, dim3(cdiv(D, 64)), dim3(kT), 0, stream, part, nchunk, D, out);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

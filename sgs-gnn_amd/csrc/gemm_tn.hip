@@ -60,7 +60,87 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce(const float* __restrict__ 
     C[i] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tall-K variant (K >= 8192): the weight gradient of the scorer's fc1, dW1a = dv^T feat with K = q = 100 000 rows and
+// M = N = 256 (training_hybrid.py's learned backward).  The vendor GEMM runs this shape at 42 TFLOP/s (310 us) and the
+// one-tile-per-wave kernel above needs two loads per MFMA.  Here a wave owns a 128 x 64 output tile (8 accumulators) and a
+// K-slice: per k2-step ONE 16-byte load of A (row k, columns m0 + 4 l31 .. + 3 -> the A operands of four M-tiles whose rows
+// interleave with stride 4) and ONE 8-byte load of B (two N-tiles) feed 8 MFMAs, i.e. 0.25 loads / 24 B per lane per 8
+// MFMAs, all of it coalesced row segments.  Eight k2-steps are in flight per wave (two register stages of four), enough to
+// cover L2 latency with a single wave per SIMD, so K is split only as far as needed to give every SIMD one wave.
+constexpr int kTallK = 8192;
+constexpr int kTallU = 4;                    // k2-steps per register stage
+
+__global__ void __launch_bounds__(64) gemm_tn_tall_tile(const float* __restrict__ A, const float* __restrict__ B, int64_t K, int M, int N,
+                                                       int ksplit, float* __restrict__ slab) {
+    const int lane = threadIdx.x, kh = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 64, s = blockIdx.z;
+    const int ia = m0 + 4 * l31, jb = n0 + 2 * l31;
+    const bool aok = ia < M, bok = jb < N;         // M % 4 == 0 and N % 2 == 0 (checked by the launcher): whole vectors are in or out
+    const int64_t per = ((K + ksplit - 1) / ksplit + 1) & ~int64_t(1);      // even slice length
+    const int64_t k0 = s * per, k1 = (k0 + per < K) ? k0 + per : K;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float2 z2 = make_float2(0.f, 0.f);
+    auto load = [&](int64_t k, float4 (&a)[kTallU], float2 (&b)[kTallU]) {
+#pragma unroll
+        for (int u = 0; u < kTallU; ++u) {
+            const int64_t kk = k + 2 * u + kh;
+            const bool in = kk < k1;
+            a[u] = (aok && in) ? *reinterpret_cast<const float4*>(A + kk * M + ia) : z4;
+            b[u] = (bok && in) ? *reinterpret_cast<const float2*>(B + kk * N + jb) : z2;
+        }
+    };
+    auto mma = [&](const float4 (&a)[kTallU], const float2 (&b)[kTallU]) {
+#pragma unroll
+        for (int u = 0; u < kTallU; ++u) {
+            const float av[4] = {a[u].x, a[u].y, a[u].z, a[u].w};
+            const float bv[2] = {b[u].x, b[u].y};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int w = 0; w < 2; ++w) acc[t][w] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[w], acc[t][w], 0, 0, 0);
+        }
+    };
+    float4 a0[kTallU], a1[kTallU];
+    float2 b0[kTallU], b1[kTallU];
+    load(k0, a0, b0);
+#pragma unroll 1
+    for (int64_t k = k0; k < k1; k += 4 * kTallU) {
+        load(k + 2 * kTallU, a1, b1);                       // rows past k1 load zeros
+        mma(a0, b0);
+        load(k + 4 * kTallU, a0, b0);
+        mma(a1, b1);
+    }
+    float* out = slab + static_cast<int64_t>(s) * M * N;
+    // accumulator register r of tile (t, w): row m0 + 4 ((r & 3) + 8 (r >> 2) + 4 kh) + t, column n0 + 2 l31 + w
+    if (bok) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + t;
+                if (row < M) *reinterpret_cast<float2*>(out + static_cast<int64_t>(row) * N + jb) = make_float2(acc[t][0][r], acc[t][1][r]);
+            }
+    }
+}
+
+inline bool use_tall(int64_t K, int64_t M, int64_t N) { return K >= kTallK && M % 4 == 0 && N % 2 == 0; }
+inline int pick_ksplit_tall(int64_t K, int64_t M, int64_t N) {
+    const int64_t tiles = cdiv(M, 128) * cdiv(N, 64);
+    int ks = 1;
+    while (ks < 512 && tiles * ks < 1024 && K / (ks * 2) >= 256) ks *= 2;     // one wave per SIMD (two are slower: twice the slab traffic), >= 256 rows per slice
+    return ks;
+}
+
 inline int pick_ksplit(int64_t K, int64_t M, int64_t N) {
+    if (use_tall(K, M, N)) return pick_ksplit_tall(K, M, N);
     const int64_t tiles = cdiv(M, 32) * cdiv(N, 32);
     int ks = 1;
     while (ks < 64 && tiles * ks < 1024 && K / (ks * 2) >= 64) ks *= 2;      // fill ~1024 SIMDs, keep >= 64 rows per slice
@@ -90,8 +170,12 @@ int sgs_gemm_tn(const float* A, const float* B, int64_t K, int64_t M, int64_t N,
     Carver cv(ws);
     float* slab = cv.take<float>(static_cast<size_t>(ks) * M * N);
     float* dst = ks == 1 ? C : slab;
-    hipLaunchKernelGGL(gemm_tn_tile, dim3(cdiv(M, 32), cdiv(N, 32), ks), dim3(64), 0, stream, A, B, K, static_cast<int>(M),
-                       static_cast<int>(N), ks, dst);
+    if (use_tall(K, M, N))
+        hipLaunchKernelGGL(gemm_tn_tall_tile, dim3(cdiv(M, 128), cdiv(N, 64), ks), dim3(64), 0, stream, A, B, K, static_cast<int>(M),
+                           static_cast<int>(N), ks, dst);
+    else
+        hipLaunchKernelGGL(gemm_tn_tile, dim3(cdiv(M, 32), cdiv(N, 32), ks), dim3(64), 0, stream, A, B, K, static_cast<int>(M),
+                           static_cast<int>(N), ks, dst);
     if (ks > 1) hipLaunchKernelGGL(gemm_tn_reduce, dim3(cdiv(M * N, 256)), dim3(256), 0, stream, slab, M * N, ks, C);
     SGS_LAUNCH_OK();
     return SGS_OK;

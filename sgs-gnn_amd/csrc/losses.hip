@@ -76,6 +76,18 @@ __global__ void __launch_bounds__(1024) masked_correct_pair(const float* __restr
     }
 }
 
+// Hands a few device words to the HOST without a copy engine round trip: `dst` is pinned, device-mapped host memory; the
+// payload is written first, then the sequence word (the RNG epoch, which changes on every graph replay) with release
+// semantics at system scope, so a host thread that polls the sequence word sees the payload.  Used for the gate.
+__global__ void publish_words(const int32_t* __restrict__ src, int n, const uint64_t* __restrict__ seq, int32_t* dst) {
+    if (threadIdx.x < n) __hip_atomic_store(dst + threadIdx.x, src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        __hip_atomic_store(dst + n, static_cast<int32_t>(seq ? seq[0] : 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---------------------------------------------------------------- masked cross entropy
 // rowloss[i] = lse_i - logit_i[y_i] on train rows (0 elsewhere); row_lse kept for backward.
 __global__ void __launch_bounds__(kT) ce_rows(const float* __restrict__ logits, int64_t N, int64_t C, const int64_t* __restrict__ y,
@@ -275,6 +287,14 @@ int sgs_masked_correct_pair(const float* logits_a, const float* logits_b, int64_
     SGS_REQUIRE(logits_a && logits_b && y && train_mask, SGS_EINVAL, "sgs_masked_correct_pair: null pointer");
     hipLaunchKernelGGL(masked_correct_pair, dim3(static_cast<unsigned>(cdiv(N, 16)), 2), dim3(1024), 0, stream, logits_a, logits_b, N, C, y, train_mask,
                        correct4);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_publish_to_host(const int32_t* src_dev, int64_t n, const uint64_t* seq_dev, int32_t* dst_host_mapped, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(n > 0 && n <= 63 && src_dev && dst_host_mapped, SGS_EINVAL, "sgs_publish_to_host: bad arguments");
+    hipLaunchKernelGGL(publish_words, dim3(1), dim3(64), 0, stream, src_dev, static_cast<int>(n), seq_dev, dst_host_mapped);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

@@ -79,6 +79,11 @@ class StepGraphs:
         # with the stream it was created on, and a capture must not meet nodes from the legacy default stream
         self.stream = torch.cuda.Stream(device=self.device)
         self.one = torch.ones((), dtype=torch.float32, device=self.device)      # root gradient: saves autograd's ones_like fill per backward
+        self.loss_sum = torch.zeros((), dtype=torch.float32, device=self.device)  # replayed steps add their loss here (read once per epoch)
+        # gate read-back of a replayed step without a copy-engine round trip: G1 ends by publishing the counts to pinned,
+        # device-mapped host memory (sgs_publish_to_host) and the trainer polls the sequence word
+        self.host_gate = torch.zeros(8, dtype=torch.int32).pin_memory()
+        self.host_gate_np = self.host_gate.numpy()
         self.table = {}          # batch key -> _Captured | "seen"
         self.cfg = self._config_key()
 
@@ -156,6 +161,7 @@ class StepGraphs:
                 c.loss.backward(gradient=self.one)
                 if self.optimizers is not None:
                     self.optimizers[1].step()                      # optimizer_gnn (training_hybrid.py:161)
+                self.loss_sum.add_(c.loss.detach())
             c.grads = self._grads()
             c.loss = c.loss.detach()
             self._clear_grads()
@@ -163,6 +169,8 @@ class StepGraphs:
         with torch.cuda.graph(c.g1, stream=self.stream):
             self.epoch_word.add_(1)
             st = sampled_forward(self.pipeline, a, self.model, batch, self.q, self.use_checkpoint)
+            if st.cbuf is not None:
+                ops.publish_to_host(st.cbuf, 4, self.epoch_word, self.host_gate)
         pool = c.g1.pool() if _DEBUG != "nopool" else None
         c.cbuf = st.cbuf
         # static views of the replay's own draws and outputs (private-pool memory is never reused after the
@@ -178,6 +186,7 @@ class StepGraphs:
             if self.optimizers is not None:
                 self.optimizers[0].step()                          # optimizer_edge_prob, then optimizer_gnn (:136-137)
                 self.optimizers[1].step()
+            self.loss_sum.add_(loss_l.detach())
         c.grads_l = self._grads()
         c.loss_l = loss_l.detach()
         self._clear_grads()
@@ -189,6 +198,7 @@ class StepGraphs:
                 loss_r.backward(gradient=self.one)
                 if self.optimizers is not None:
                     self.optimizers[1].step()                      # optimizer_gnn only (:141)
+                self.loss_sum.add_(loss_r.detach())
             c.grads_r = self._grads()
             c.loss_r = loss_r.detach()
             self._clear_grads()
@@ -209,8 +219,9 @@ class StepGraphs:
             return _EagerHandle(self, batch)
         if c == "seen":
             c = self.table[key] = self._capture(batch, key)
+        seq0 = int(self.host_gate_np[4])
         c.g1.replay()
-        return _ReplayHandle(self, c)
+        return _ReplayHandle(self, c, seq0)
 
     def step(self, batch, epoch=0):
         """Single-process convenience: forward, gate read-back, backward.  Returns (loss, learned_won | None)."""
@@ -222,7 +233,7 @@ class StepGraphs:
             return loss, None
         won = True
         if h.cbuf is not None:
-            cnt = h.cbuf.tolist()                      # the step's one host read-back (gate)
+            cnt = h.gate_counts()                      # the step's one host read-back (gate)
             won = cnt[0] > cnt[2]
         loss = h.backward(won)
         if self.optimizers is not None and not h.opt_in_graph:
@@ -233,11 +244,25 @@ class StepGraphs:
 
 
 class _ReplayHandle:
-    __slots__ = ("sg", "c", "sampled", "cbuf", "opt_in_graph")
+    __slots__ = ("sg", "c", "sampled", "cbuf", "opt_in_graph", "seq0", "loss_on_device")
 
-    def __init__(self, sg, c):
+    def __init__(self, sg, c, seq0):
         self.sg, self.c, self.sampled, self.cbuf = sg, c, c.sampled, c.cbuf
         self.opt_in_graph = sg.optimizers is not None      # the backward graphs end with the optimiser steps
+        self.seq0 = seq0
+        self.loss_on_device = True                         # the graphs add their loss to sg.loss_sum
+
+    def gate_counts(self):
+        """[#correct learned, #train, #correct random, #train] of this replay: polls the pinned gate words G1 publishes
+        (falls back to a stream synchronisation if the sequence word has not moved after a while)."""
+        g = self.sg.host_gate_np
+        for _ in range(200000):
+            if g[4] != self.seq0:
+                return [int(g[0]), int(g[1]), int(g[2]), int(g[3])]
+        torch.cuda.current_stream().synchronize()
+        if g[4] == self.seq0:
+            raise RuntimeError("sgs_gnn_amd: the replayed step did not publish its gate counts")
+        return [int(g[0]), int(g[1]), int(g[2]), int(g[3])]
 
     def backward(self, learned):
         c, sg = self.c, self.sg
@@ -255,12 +280,13 @@ class _ReplayHandle:
 
 class _EagerHandle:
     """First visit of a partition: the same segments launched eagerly on the capture stream (warm-up)."""
-    __slots__ = ("sg", "batch", "sampled", "cbuf", "st", "cur", "opt_in_graph")
+    __slots__ = ("sg", "batch", "sampled", "cbuf", "st", "cur", "opt_in_graph", "loss_on_device")
 
     def __init__(self, sg, batch):
         from .training import sampled_forward
         self.sg, self.batch = sg, batch
         self.opt_in_graph = False
+        self.loss_on_device = False
         self.sampled = batch.edge_index.shape[1] > sg.q
         self.cbuf, self.st = None, None
         self.cur = torch.cuda.current_stream()
@@ -270,6 +296,9 @@ class _EagerHandle:
                 self.st = sampled_forward(sg.pipeline, sg.args, sg.model, batch, sg.q, sg.use_checkpoint)
             self.cur.wait_stream(sg.stream)
             self.cbuf = self.st.cbuf
+
+    def gate_counts(self):
+        return self.cbuf.tolist()[:4]
 
     def backward(self, learned):
         from .training import _ce, learned_loss

@@ -173,6 +173,9 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
     temperature = 1.0
     condtional_update = 0
     total_update = 0
+    h = None
+    if graphs is not None:
+        graphs.loss_sum.zero_()
     for batch in cluster_loader:
         if not _has_train_nodes(batch):
             continue
@@ -193,7 +196,11 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
                 update_edge_mlp = True
                 counts = None
                 any_learned = False
-                if args.conditional:
+                if args.conditional and h is not None and sync is None:
+                    counts = h.gate_counts() + [0]                                 # replay: polled from pinned host memory
+                    counts = [counts[0:2], counts[2:4]]
+                    update_edge_mlp = counts[0][0] > counts[1][0]
+                elif args.conditional:
                     cbuf = st.cbuf if h is None else h.cbuf
                     if sync is not None:            # N > 1: does ANY rank's gate choose "learned"? (device-side, no extra sync)
                         cbuf[4:5] = sync.any_learned((cbuf[0:1] > cbuf[2:3]).to(torch.int32))
@@ -283,8 +290,13 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
         else:
             raise ValueError("Invalid mode. Choose 'learned', 'random', or 'full'.")
 
-        # (.clone(): under HIP-graph replay `loss` is a static buffer the next replay overwrites)
-        total_loss = loss.detach().clone() if total_loss is None else total_loss + loss.detach()
+        if h is not None and mode == 'learned' and h.loss_on_device:
+            pass                            # replayed graphs add their loss to graphs.loss_sum on the device
+        else:
+            total_loss = loss.detach().clone() if total_loss is None else total_loss + loss.detach()
 
-    mean_loss = (float(total_loss) if total_loss is not None else 0.0) / len(cluster_loader)
+    loss_total = float(total_loss) if total_loss is not None else 0.0
+    if graphs is not None:
+        loss_total += float(graphs.loss_sum)
+    mean_loss = loss_total / len(cluster_loader)
     return mean_loss, temperature, condtional_update, total_update

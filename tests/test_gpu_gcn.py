@@ -144,7 +144,8 @@ def test_propagate_is_run_to_run_deterministic(pkg):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
-@pytest.mark.parametrize("K,M,N", [(1013, 256, 602), (1013, 41, 256), (7, 5, 3), (2000, 256, 256), (333, 70, 8710), (64, 32, 32), (1, 4, 4)])
+@pytest.mark.parametrize("K,M,N", [(1013, 256, 602), (1013, 41, 256), (7, 5, 3), (2000, 256, 256), (333, 70, 8710), (64, 32, 32), (1, 4, 4),
+                                   (20011, 256, 256), (9001, 132, 70), (8192, 4, 2)])
 def test_gemm_tn_weight_gradient(pkg, K, M, N):
     """dW = dY^T X on the f32 matrix cores vs fp64."""
     g = torch.Generator().manual_seed(K + M + N)
@@ -158,6 +159,6 @@ def test_gemm_tn_weight_gradient(pkg, K, M, N):
     y.backward(dY.to(DEV))
     ref = dY.double().t() @ X.double()
     err = float((W.grad.cpu().double() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
-    assert err < 2e-6, err
+    assert err < (2e-6 if K < 8192 else 6e-6), err      # tall-K kernel: longer fp32 chains per slice
     refx = dY.double() @ W.detach().cpu().double()
     assert float((xd.grad.cpu().double() - refx).abs().max()) / (float(refx.abs().max()) + 1e-12) < 1e-5

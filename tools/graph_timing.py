@@ -29,14 +29,25 @@ def t(g, reps=20):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
 
+import time
+def host_us(g, reps=20):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.replay()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    return (t1 - t0) / reps * 1e6
+
 rows = []
 for bt in pool:
     from sgs_gnn_amd.stepgraph import _batch_key
     c = sg.table[_batch_key(bt)]
     E = bt.edge_index.shape[1]
     if c.sampled:
-        rows.append(dict(E=E, g1_us=round(t(c.g1), 1), g2l_us=round(t(c.g2l), 1), g2r_us=round(t(c.g2r), 1)))
+        rows.append(dict(E=E, g1_us=round(t(c.g1), 1), g2l_us=round(t(c.g2l), 1), g2r_us=round(t(c.g2r), 1),
+                         g1_host_launch_us=round(host_us(c.g1), 1), g2r_host_launch_us=round(host_us(c.g2r), 1)))
     else:
-        rows.append(dict(E=E, g_us=round(t(c.g1), 1)))
+        rows.append(dict(E=E, g_us=round(t(c.g1), 1), g_host_launch_us=round(host_us(c.g1), 1)))
 for r in sorted(rows, key=lambda r: r["E"]):
     print(json.dumps(r))
