@@ -759,15 +759,17 @@ __global__ void __launch_bounds__(kT) endpoint_reduce(const float* __restrict__ 
 // Small-N variant: a 4-wave workgroup per node; the node's out-row then in-row entries form one list
 // that the waves stride with four independent row gathers in flight each; partial sums meet in LDS
 // in a fixed order (deterministic).
-template <int VEC, bool HAS_T>
-__global__ void __launch_bounds__(kT) endpoint_reduce_rowblock(const float* __restrict__ Mo, const float* __restrict__ Mi,
+// NW waves per node: 4 for moderate rows, 16 when rows are long -- a power-law partition has hub nodes with thousands of
+// incident sampled edges, and with 4 waves those few workgroups set the kernel's duration (92 us -> see profiles).
+template <int VEC, bool HAS_T, int NW>
+__global__ void __launch_bounds__(64 * NW) endpoint_reduce_rowblock(const float* __restrict__ Mo, const float* __restrict__ Mi,
                                                               const float* __restrict__ T, int64_t N, int64_t H,
                                                               const int* __restrict__ in_ptr, const int* __restrict__ in_src,
                                                               const int* __restrict__ in_eid, const int* __restrict__ out_ptr,
                                                               const int* __restrict__ out_dst, const int* __restrict__ out_eid,
                                                               float sgn_out, float sgn_in, float* __restrict__ out) {
     using V = typename std::conditional<VEC == 4, float4, float>::type;
-    __shared__ float part[4][64 * VEC];
+    __shared__ float part[NW][64 * VEC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t v = blockIdx.x;
     const int ob = out_ptr[v], no = out_ptr[v + 1] - ob;
@@ -779,11 +781,11 @@ __global__ void __launch_bounds__(kT) endpoint_reduce_rowblock(const float* __re
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
         if (c0 < H) {
-            for (int k0 = wave; k0 < total; k0 += 16) {
+            for (int k0 = wave; k0 < total; k0 += 4 * NW) {
                 float m[4][VEC], t[4][VEC], sg[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int k = k0 + 4 * u;
+                    const int k = k0 + NW * u;
                     sg[u] = 0.f;
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) { m[u][j] = 0.f; t[u][j] = 1.f; }
@@ -810,7 +812,12 @@ __global__ void __launch_bounds__(kT) endpoint_reduce_rowblock(const float* __re
         for (int j = 0; j < VEC; ++j) part[wave][lane * VEC + j] = acc[j];
         __syncthreads();
         const int tt = threadIdx.x;
-        if (tt < 64 * VEC && cbase + tt < H) out[v * H + cbase + tt] = (part[0][tt] + part[1][tt]) + (part[2][tt] + part[3][tt]);
+        if (tt < 64 * VEC && cbase + tt < H) {
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < NW; g += 4) sum += (part[g][tt] + part[g + 1][tt]) + (part[g + 2][tt] + part[g + 3][tt]);
+            out[v * H + cbase + tt] = sum;
+        }
         __syncthreads();
     }
 }
@@ -998,13 +1005,17 @@ int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, i
     const dim3 blk(kT);
     if (N <= 65536 && nnz >= 8 * N) {         // few, long rows: a workgroup per node
         const dim3 grid(static_cast<unsigned>(N));
-        if (v4) {
-            if (T) hipLaunchKernelGGL((endpoint_reduce_rowblock<4, true>), grid, blk, 0, stream, M_out, M_in, T, N, H, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, sign_out, sign_in, out);
-            else   hipLaunchKernelGGL((endpoint_reduce_rowblock<4, false>), grid, blk, 0, stream, M_out, M_in, T, N, H, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, sign_out, sign_in, out);
-        } else {
-            if (T) hipLaunchKernelGGL((endpoint_reduce_rowblock<1, true>), grid, blk, 0, stream, M_out, M_in, T, N, H, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, sign_out, sign_in, out);
-            else   hipLaunchKernelGGL((endpoint_reduce_rowblock<1, false>), grid, blk, 0, stream, M_out, M_in, T, N, H, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, sign_out, sign_in, out);
-        }
+        const bool wide = nnz >= 64 * N;       // long rows (hubs with thousands of entries): 16 waves per node
+#define SGS_EPR(VEC_, HT_)                                                                                                   \
+        do {                                                                                                                    \
+            if (wide) hipLaunchKernelGGL((endpoint_reduce_rowblock<VEC_, HT_, 16>), grid, dim3(1024), 0, stream, M_out, M_in, T, N, H, in_ptr, \
+                                         in_src, in_eid, out_ptr, out_dst, out_eid, sign_out, sign_in, out);                  \
+            else      hipLaunchKernelGGL((endpoint_reduce_rowblock<VEC_, HT_, 4>), grid, blk, 0, stream, M_out, M_in, T, N, H, in_ptr,        \
+                                         in_src, in_eid, out_ptr, out_dst, out_eid, sign_out, sign_in, out);                  \
+        } while (0)
+        if (v4) { if (T) SGS_EPR(4, true); else SGS_EPR(4, false); }
+        else    { if (T) SGS_EPR(1, true); else SGS_EPR(1, false); }
+#undef SGS_EPR
         SGS_LAUNCH_OK();
         return SGS_OK;
     }

@@ -463,14 +463,15 @@ __global__ void __launch_bounds__(kT) spmm_csr(const float* __restrict__ X, int6
 // mostly empty and hub rows serialise, so a 4-wave workgroup owns a row, each wave gathers a strided
 // quarter of its nnz (8 rows in flight per wave) and the four partial sums are combined through LDS
 // in a fixed order (deterministic).
-template <int VEC>
-__global__ void __launch_bounds__(kT) spmm_csr_rowblock(const float* __restrict__ X, int64_t N, int64_t D, const int* __restrict__ ptr,
+// NW waves per row: 4, or 16 when rows are long (power-law partitions: the hub rows set the kernel's duration)
+template <int VEC, int NW>
+__global__ void __launch_bounds__(64 * NW) spmm_csr_rowblock(const float* __restrict__ X, int64_t N, int64_t D, const int* __restrict__ ptr,
                                                        const int* __restrict__ col, const float* __restrict__ val,
                                                        const float* __restrict__ diag, const float* __restrict__ bias, int act,
                                                        float drop_scale, uint32_t drop_thresh, uint64_t seed, uint32_t site,
                                                        const uint64_t* __restrict__ epoch, float* __restrict__ Y) {
     using V = typename VecT<VEC>::type;
-    __shared__ float part[4][64 * VEC];
+    __shared__ float part[NW][64 * VEC];
     seed = fold_epoch(seed, epoch);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t i = blockIdx.x;
@@ -485,10 +486,10 @@ __global__ void __launch_bounds__(kT) spmm_csr_rowblock(const float* __restrict_
         for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
         if (in) {
             int k = b + wave;
-            for (; k + 28 < e; k += 32) {            // 8 independent gathers (k, k+4, ..., k+28)
+            for (; k + 7 * NW < e; k += 8 * NW) {    // 8 independent gathers (k, k+NW, ..., k+7NW)
                 int j[8]; float w[8]; V x[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { j[u] = col[k + 4 * u]; w[u] = val[k + 4 * u]; }
+                for (int u = 0; u < 8; ++u) { j[u] = col[k + NW * u]; w[u] = val[k + NW * u]; }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const V*>(X + static_cast<int64_t>(j[u]) * D + c0);
 #pragma unroll
@@ -499,7 +500,7 @@ __global__ void __launch_bounds__(kT) spmm_csr_rowblock(const float* __restrict_
                     for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w[u], xv[v], acc[v]);
                 }
             }
-            for (; k < e; k += 4) {
+            for (; k < e; k += NW) {
                 float xv[VEC];
                 *reinterpret_cast<V*>(xv) = *reinterpret_cast<const V*>(X + static_cast<int64_t>(col[k]) * D + c0);
                 const float w = val[k];
@@ -514,7 +515,9 @@ __global__ void __launch_bounds__(kT) spmm_csr_rowblock(const float* __restrict_
         const int t = threadIdx.x;
         if (t < 64 * VEC && cbase + t < D) {
             const int64_t c = cbase + t;
-            float y = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+            float y = 0.f;
+#pragma unroll
+            for (int g = 0; g < NW; g += 4) y += (part[g][t] + part[g + 1][t]) + (part[g + 2][t] + part[g + 3][t]);
             if (diag) y = fmaf(dg, X[i * D + c], y);
             if (bias) y += bias[c];
             if (act != SGS_ACT_NONE) y = fmaxf(y, 0.f);
@@ -566,8 +569,8 @@ __global__ void __launch_bounds__(kT) sddmm_csr(const float* __restrict__ A, con
 
 // Small-N variant of sddmm_csr: a 4-wave workgroup per row, waves stride the row's entries, two
 // independent dot products in flight per wave.
-template <int VEC>
-__global__ void __launch_bounds__(kT) sddmm_csr_rowblock(const float* __restrict__ A, const float* __restrict__ B, int64_t N, int64_t D,
+template <int VEC, int NW>
+__global__ void __launch_bounds__(64 * NW) sddmm_csr_rowblock(const float* __restrict__ A, const float* __restrict__ B, int64_t N, int64_t D,
                                                         const int* __restrict__ ptr, const int* __restrict__ col,
                                                         const int* __restrict__ eid, float* __restrict__ g, float* __restrict__ gdiag) {
     using V = typename VecT<VEC>::type;
@@ -587,13 +590,13 @@ __global__ void __launch_bounds__(kT) sddmm_csr_rowblock(const float* __restrict
         return acc;
     };
     int k = b + wave;
-    for (; k + 4 < e; k += 8) {
-        float d0 = dot(col[k]), d1 = dot(col[k + 4]);
+    for (; k + NW < e; k += 2 * NW) {
+        float d0 = dot(col[k]), d1 = dot(col[k + NW]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { d0 += __shfl_xor(d0, o, 64); d1 += __shfl_xor(d1, o, 64); }
-        if (lane == 0) { g[eid[k]] = d0; g[eid[k + 4]] = d1; }
+        if (lane == 0) { g[eid[k]] = d0; g[eid[k + NW]] = d1; }
     }
-    for (; k < e; k += 4) {
+    for (; k < e; k += NW) {
         const float d0 = wave_sum_all(dot(col[k]));
         if (lane == 0) g[eid[k]] = d0;
     }
@@ -890,12 +893,20 @@ int sgs_spmm_csr(const float* X, int64_t N, int64_t D, int64_t nnz, const int32_
     const uint32_t th = dropout_thresh(p_drop);
     if (act == SGS_ACT_RELU_DROPOUT && p_drop == 0.f) act = SGS_ACT_RELU;
     if (N <= 65536 && nnz >= 16 * N) {        // few, long rows: a workgroup per row
-        if (vec == 4)
-            hipLaunchKernelGGL((spmm_csr_rowblock<4>), dim3(static_cast<unsigned>(N)), dim3(kT), 0, stream, X, N, D, ptr, col, val,
-                               diag, bias, act, scale, th, seed, site, epoch_ptr(), Y);
+        const bool wide = nnz >= 256 * N;      // very long rows only: at ~100 entries per row the 16-wave form measured 5 % slower here
+        const dim3 g_(static_cast<unsigned>(N));
+        if (vec == 4 && wide)
+            hipLaunchKernelGGL((spmm_csr_rowblock<4, 16>), g_, dim3(1024), 0, stream, X, N, D, ptr, col, val, diag, bias, act, scale, th, seed,
+                               site, epoch_ptr(), Y);
+        else if (vec == 4)
+            hipLaunchKernelGGL((spmm_csr_rowblock<4, 4>), g_, dim3(kT), 0, stream, X, N, D, ptr, col, val, diag, bias, act, scale, th, seed,
+                               site, epoch_ptr(), Y);
+        else if (wide)
+            hipLaunchKernelGGL((spmm_csr_rowblock<1, 16>), g_, dim3(1024), 0, stream, X, N, D, ptr, col, val, diag, bias, act, scale, th, seed,
+                               site, epoch_ptr(), Y);
         else
-            hipLaunchKernelGGL((spmm_csr_rowblock<1>), dim3(static_cast<unsigned>(N)), dim3(kT), 0, stream, X, N, D, ptr, col, val,
-                               diag, bias, act, scale, th, seed, site, epoch_ptr(), Y);
+            hipLaunchKernelGGL((spmm_csr_rowblock<1, 4>), g_, dim3(kT), 0, stream, X, N, D, ptr, col, val, diag, bias, act, scale, th, seed,
+                               site, epoch_ptr(), Y);
     } else {
         DISPATCH_VEC_LPR(spmm_csr, vec, lpr, N, X, N, D, ptr, col, val, diag, bias, act, scale, th, seed, site, epoch_ptr(), Y);
     }
@@ -912,8 +923,12 @@ int sgs_sddmm_csr(const float* A, const float* B, int64_t N, int64_t D, int64_t 
     const int vec = (D % 4 == 0 && aligned16(A) && aligned16(B)) ? 4 : 1;
     const int lpr = pick_lpr(D, vec);
     if (N <= 65536 && nnz >= 16 * N) {
-        if (vec == 4) hipLaunchKernelGGL((sddmm_csr_rowblock<4>), dim3(static_cast<unsigned>(N)), dim3(kT), 0, stream, A, B, N, D, ptr, col, eid, g, gdiag);
-        else          hipLaunchKernelGGL((sddmm_csr_rowblock<1>), dim3(static_cast<unsigned>(N)), dim3(kT), 0, stream, A, B, N, D, ptr, col, eid, g, gdiag);
+        const bool wide = nnz >= 64 * N;
+        const dim3 g_(static_cast<unsigned>(N));
+        if (vec == 4 && wide) hipLaunchKernelGGL((sddmm_csr_rowblock<4, 16>), g_, dim3(1024), 0, stream, A, B, N, D, ptr, col, eid, g, gdiag);
+        else if (vec == 4)    hipLaunchKernelGGL((sddmm_csr_rowblock<4, 4>), g_, dim3(kT), 0, stream, A, B, N, D, ptr, col, eid, g, gdiag);
+        else if (wide)        hipLaunchKernelGGL((sddmm_csr_rowblock<1, 16>), g_, dim3(1024), 0, stream, A, B, N, D, ptr, col, eid, g, gdiag);
+        else                  hipLaunchKernelGGL((sddmm_csr_rowblock<1, 4>), g_, dim3(kT), 0, stream, A, B, N, D, ptr, col, eid, g, gdiag);
     } else {
         DISPATCH_VEC_LPR(sddmm_csr, vec, lpr, N, A, B, N, D, ptr, col, eid, g, gdiag);
     }
