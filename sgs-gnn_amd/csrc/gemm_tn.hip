@@ -66,10 +66,10 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce(const float* __restrict__ 
 // one-tile-per-wave kernel above needs two loads per MFMA.  Here a wave owns a 128 x 64 output tile (8 accumulators) and a
 // K-slice: per k2-step ONE 16-byte load of A (row k, columns m0 + 4 l31 .. + 3 -> the A operands of four M-tiles whose rows
 // interleave with stride 4) and ONE 8-byte load of B (two N-tiles) feed 8 MFMAs, i.e. 0.25 loads / 24 B per lane per 8
-// MFMAs, all of it coalesced row segments.  Eight k2-steps are in flight per wave (two register stages of four), enough to
+// MFMAs, all of it coalesced row segments.  Sixteen k2-steps are in flight per wave (two register stages of eight), enough to
 // cover L2 latency with a single wave per SIMD, so K is split only as far as needed to give every SIMD one wave.
 constexpr int kTallK = 8192;
-constexpr int kTallU = 4;                    // k2-steps per register stage
+constexpr int kTallU = 8;                    // k2-steps per register stage
 
 __global__ void __launch_bounds__(64) gemm_tn_tall_tile(const float* __restrict__ A, const float* __restrict__ B, int64_t K, int M, int N,
                                                        int ksplit, float* __restrict__ slab) {

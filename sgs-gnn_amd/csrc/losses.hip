@@ -227,33 +227,49 @@ __global__ void __launch_bounds__(kT) reg_raw_final(const float* __restrict__ pa
 }
 
 // Per sampled edge: dw[j] and the gradient rows wrt logits[src] (Gs) and logits[dst] (Gd).
+// One 16-lane group per sampled edge (16 edges per workgroup): the group's lanes stride the C logit columns, so the two
+// [q, C] gradient-row arrays are written as contiguous segments (a thread-per-edge loop writes them with a stride of C
+// floats: 69 us at q = 100 000, C = 41).  The three dot products are reduced inside the group in a fixed order.
 __global__ void __launch_bounds__(kT) reg_bwd_edges(const float* __restrict__ w, const int64_t* __restrict__ sei, int64_t q,
                                                    const float* __restrict__ logits, int64_t C, const int64_t* __restrict__ y,
                                                    const uint8_t* __restrict__ tm, const float* __restrict__ out, float coef1,
                                                    float coef2, float q_norm, const float* __restrict__ grad_loss,
                                                    float* __restrict__ dw, float* __restrict__ Gs, float* __restrict__ Gd) {
-    const int64_t j = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
-    if (j >= q) return;
+    const int sub = threadIdx.x & 15;
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * (kT / 16) + (threadIdx.x >> 4);
+    const bool live = j < q;
+    const int64_t jj = live ? j : 0;
     const float gl = grad_loss[0];
-    const int64_t s = sei[j], d = sei[q + j];
+    const int64_t s = sei[jj], d = sei[q + jj];
     const float* x = logits + s * C;
     const float* yv = logits + d * C;
-    const EdgeTerms t = edge_dot(x, yv, C);
-    const float den2 = fmaxf(t.nx * t.ny, 1e-16f);
+    float dot = 0.f, nx = 0.f, ny = 0.f;
+    for (int64_t c = sub; c < C; c += 16) {
+        const float a = x[c], b = yv[c];
+        dot = fmaf(a, b, dot); nx = fmaf(a, a, nx); ny = fmaf(b, b, ny);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {                 // all 16 lanes of a group end with the same sums
+        dot += __shfl_xor(dot, o, 64); nx += __shfl_xor(nx, o, 64); ny += __shfl_xor(ny, o, 64);
+    }
+    if (!live) return;
+    const float den2 = fmaxf(nx * ny, 1e-16f);
     const float inv = 1.0f / sqrtf(den2);
-    const float cs = t.dot * inv;
+    const float cs = dot * inv;
     const float wj = w[j];
     const float r = 2.0f * (wj - cs) / q_norm * coef2 * gl;                        // dL/d(w - cos); q_norm = global #sampled edges
-    float g = r;
-    if (coef1 != 0.f && out[3] > 1.f && tm[s] && tm[d]) {
-        const float tgt = (y[s] == y[d]) ? 1.f : 0.f;
-        g += coef1 * gl * (wj - tgt) / fmaxf((1.f - wj) * wj, 1e-12f) / out[2];   // torch's BCE backward
+    if (sub == 0) {
+        float g = r;
+        if (coef1 != 0.f && out[3] > 1.f && tm[s] && tm[d]) {
+            const float tgt = (y[s] == y[d]) ? 1.f : 0.f;
+            g += coef1 * gl * (wj - tgt) / fmaxf((1.f - wj) * wj, 1e-12f) / out[2];   // torch's BCE backward
+        }
+        dw[j] = g;
     }
-    dw[j] = g;
     // d cos / d x = y * inv - cos * x / |x|^2  (only while the eps clamp is inactive, as autograd)
-    const bool clamped = t.nx * t.ny < 1e-16f;
-    const float cx = clamped ? 0.f : cs / t.nx, cy = clamped ? 0.f : cs / t.ny;
-    for (int64_t c = 0; c < C; ++c) {
+    const bool clamped = nx * ny < 1e-16f;
+    const float cx = clamped ? 0.f : cs / nx, cy = clamped ? 0.f : cs / ny;
+    for (int64_t c = sub; c < C; c += 16) {
         const float a = x[c], b = yv[c];
         Gs[j * C + c] = -r * (b * inv - cx * a);
         Gd[j * C + c] = -r * (a * inv - cy * b);
@@ -367,7 +383,7 @@ int sgs_edge_reg_bwd(const float* w, const int64_t* sampled_edge_index, int64_t 
     if (q == 0) return SGS_OK;
     SGS_REQUIRE(w && sampled_edge_index && logits && y && train_mask && out && grad_loss && dw && Gs && Gd, SGS_EINVAL,
                 "sgs_edge_reg_bwd: null pointer");
-    hipLaunchKernelGGL(reg_bwd_edges, dim3(cdiv(q, kT)), dim3(kT), 0, stream, w, sampled_edge_index, q, logits, C, y, train_mask, out,
+    hipLaunchKernelGGL(reg_bwd_edges, dim3(cdiv(q, kT / 16)), dim3(kT), 0, stream, w, sampled_edge_index, q, logits, C, y, train_mask, out,
                        coef1, coef2, static_cast<float>(q_global), grad_loss, dw, Gs, Gd);
     SGS_LAUNCH_OK();
     return SGS_OK;
