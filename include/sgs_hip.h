@@ -258,10 +258,11 @@ int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, void* ws, size_
  * sgs_edge_score_bwd_core runs over an explicit list of active edges (hybrid / two-pass: the q
  * sampled edges -- every other edge has exactly zero upstream gradient; NULL = all E edges in
  * order) and RECOMPUTES the hidden layer instead of storing it.  It writes, per active row j:
- *   dv[j,:]  = dL/d(fc1 pre-activation)       hdz[j,:] = dz_j * hidden_j   (colsum -> d w2)
- *   dz[j]    = grad_p_j p_j (1-p_j)  (sum -> d b2)          feat[j,:] = x_s * x_d
- * from which the host forms  d W1a = dv^T feat,  d b1 = colsum(dv),  dfeat = dv W1a  (library
- * GEMMs) and the two endpoint reductions below.
+ *   dv[j,:]  = dL/d(fc1 pre-activation)       dz[j] = grad_p_j p_j (1-p_j)  (sum -> d b2)       feat[j,:] = x_s * x_d
+ * and, per tile of sgs_edge_score_bwd_tile() (= 64) consecutive active rows, ONE row of
+ *   hdz_part[tile,:] = sum_{j in tile} dz_j * hidden_j          (rows sum to d w2; hidden is never written per edge)
+ * from which the host forms  d W1a = dv^T feat (sgs_gemm_tn),  d b1 = colsum(dv),  d w2 = colsum(hdz_part),
+ * dfeat = dv W1a (library GEMM) and the two endpoint reductions below.
  *
  * sgs_endpoint_reduce: out[v,:] = sum_{k in out-row v} sign_out M_out[out_eid[k],:] (* T[out_dst[k],:])
  *                               + sum_{k in in-row v}  sign_in  M_in[in_eid[k],:]   (* T[in_src[k],:])
@@ -270,6 +271,7 @@ int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, void* ws, size_
  *   d codes (direct) = reduce(dfeat, dfeat, T = codes, +1, +1);   d U = reduce(dv, dv, NULL, +1, -1).
  * ---------------------------------------------------------------------------------- */
 size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H, int64_t E);   /* E = 0 for the backward core */
+int sgs_edge_score_bwd_tile(void);              /* active rows per hdz_part row (64) */
 void sgs_edge_score_set_variant(int variant);   /* forward kernel: -1 = automatic (default: 3 when E >= 65 536, else 1),
                                                   * 0 = LDS-tiled, 1 = register-streaming (32-edge wave tile), 2 = weight-stationary
                                                   * persistent, 3 = register-streaming with a 64-edge wave tile; all give the same p */
@@ -280,7 +282,7 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
 int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index,
                             int64_t E, int64_t edge_id_offset, const int64_t* active_eid, int64_t n_active, const float* grad_p,
                             const float* W1, const float* b1, const float* w2, const float* b2, float p_drop,
-                            uint64_t seed, uint32_t site, float* dv, float* hdz, float* dz, float* feat, void* ws,
+                            uint64_t seed, uint32_t site, float* dv, float* hdz_part, float* dz, float* feat, void* ws,
                             size_t ws_bytes, sgs_stream_t stream);
 int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, int64_t N, int64_t H, int64_t nnz,
                         const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid, const int32_t* out_ptr,
@@ -361,11 +363,17 @@ int sgs_scatter_by_eid(const float* in_order, const int32_t* eid, int64_t n, flo
  * Weight-gradient GEMM of the node-level Linear layers: C[M,N] = A^T B, A [K,M], B [K,N] row-major,
  * K = number of graph nodes (dW = dY^T X for GCNConv.lin, model.py:94-95,151-153).  fp32 MFMA fed from
  * coalesced global reads, split-K with a fixed-order combine (deterministic).  Skinny shapes only (the
- * vendor GEMM serves the rest): meant for M, N <= ~1k.
+ * vendor GEMM serves the rest): meant for M, N <= ~1k.  K >= 8192 (with M % 4 == 0, N % 2 == 0) takes a tall-K kernel:
+ * 128 x 64 output tile and a K-slice per wave, one 16-B + one 8-B load per 8 MFMAs (dW1a = dv^T feat, K = q rows).
  * ---------------------------------------------------------------------------------- */
 size_t sgs_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N);
 int sgs_gemm_tn(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, void* ws, size_t ws_bytes,
                 sgs_stream_t stream);
+/* Same product with the column sums of A as a by-product (colsum_A [M]; d b1 = colsum(dv) of the scorer's backward rides
+ * on d W1a = dv^T feat): only for the shapes the tall-K kernel serves with a split -- ask sgs_gemm_tn_can_colsum first. */
+int sgs_gemm_tn_can_colsum(int64_t K, int64_t M, int64_t N);
+int sgs_gemm_tn_colsum(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, float* colsum_A, void* ws,
+                       size_t ws_bytes, sgs_stream_t stream);
 
 /* ----------------------------------------------------------------------------------
  * Optimiser (training_hybrid.py:22-27, 135-141: two torch.optim.Adam steps per batch).

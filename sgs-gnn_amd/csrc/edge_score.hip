@@ -64,7 +64,7 @@ struct ScoreArgs {
     float* p_out;            // forward: [n]
     const float* gp;         // backward: [n]
     float* dv;               // backward: [n,H]  dL/d(pre-activation)
-    float* hdz;              // backward: [n,H]  dz * dropped hidden  (column-sums to dw2)
+    float* hdz;              // backward: [cdiv(n,64), H] per-tile column sums of dz * dropped hidden (rows sum to dw2)
     float* dz;               // backward: [n]
     float* feat;             // backward: [n,H]  x_s * x_d
 };
@@ -241,9 +241,11 @@ __global__ void __launch_bounds__(kT, 3) edge_score_kernel(ScoreArgs a) {
         return;
     }
     // ---- backward epilogue: dz = gp p (1-p);  dv = dz w2 relu' keep scale;  hdz = dz hd
-    const float dzv = live ? a.gp[r] * p * (1.0f - p) : 0.f;
+    // hdz is only ever column-summed (d w2 = sum_e dz_e hd_e): instead of writing [n, H] and reading it back, every
+    // workgroup reduces its 64 edges in registers / LDS and writes ONE row of partial sums, hdz_part[blockIdx.x][:].
+    const float dzv = live ? a.gp[r] * p * (1.0f - p) : 0.f;                     // 0 on the padding rows of the last tile
     if (live && hh == 0 && kh == 0) a.dz[r] = dzv;
-    if (!live) return;
+    float* colpart = Wt_s0;                                                      // [2 edge groups][HP]: the operand stages are dead
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
 #pragma unroll
@@ -261,11 +263,20 @@ __global__ void __launch_bounds__(kT, 3) edge_score_kernel(ScoreArgs a) {
                     dv4[j] = dzv * w4[j] * m;
                     hz4[j] = dzv * hd;
                 }
-                *reinterpret_cast<float4*>(a.dv + r * H + hb) = make_float4(dv4[0], dv4[1], dv4[2], dv4[3]);
-                *reinterpret_cast<float4*>(a.hdz + r * H + hb) = make_float4(hz4[0], hz4[1], hz4[2], hz4[3]);
+                if (live) *reinterpret_cast<float4*>(a.dv + r * H + hb) = make_float4(dv4[0], dv4[1], dv4[2], dv4[3]);
+                // sum over the 32 edges of this half-wave (lanes with equal kh): fixed xor tree
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float sum = hz4[j];
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                    if (l31 == 0) colpart[eg * HP + hb + j] = sum;
+                }
             }
         }
     }
+    __syncthreads();
+    for (int h = tid; h < H; h += kT) a.hdz[static_cast<int64_t>(blockIdx.x) * H + h] = colpart[h] + colpart[HP + h];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -882,6 +893,7 @@ size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H, int64_t E) {
 // whole-step throughput is equal within noise, so the fastest kernel is the default.
 static int g_score_variant = -1;   // -1: automatic (3 when the launch fills the chip with 128-edge workgroups, else 1)
 void sgs_edge_score_set_variant(int v) { g_score_variant = v; }
+int sgs_edge_score_bwd_tile(void) { return kBM; }
 
 int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
                        int64_t edge_id_offset, const float* W1, const float* b1, const float* w2, const float* b2, float p_drop,
@@ -965,18 +977,19 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
 }
 
 /* Backward core over the active rows: recomputes the hidden layer and writes
- * dv [n,H] = dL/d(fc1 pre-activation), hdz [n,H] = dz * hidden, dz [n], feat [n,H] = x_s*x_d. */
+ * dv [n,H] = dL/d(fc1 pre-activation), hdz_part [cdiv(n, 64), H] = per-64-edge-tile column sums of dz * hidden,
+ * dz [n], feat [n,H] = x_s*x_d. */
 int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
                             int64_t edge_id_offset, const int64_t* active_eid, int64_t n_active, const float* grad_p, const float* W1,
                             const float* b1, const float* w2, const float* b2, float p_drop, uint64_t seed, uint32_t site,
-                            float* dv, float* hdz, float* dz, float* feat, void* ws, size_t ws_bytes,
+                            float* dv, float* hdz_part, float* dz, float* feat, void* ws, size_t ws_bytes,
                             sgs_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (int rc = check_common("sgs_edge_score_bwd_core", N, H, E, p_drop)) return rc;
     SGS_REQUIRE(n_active >= 0 && (active_eid || n_active == E), SGS_EINVAL,
                 "sgs_edge_score_bwd_core: n_active must equal E when active_eid is NULL");
     if (n_active == 0) return SGS_OK;
-    SGS_REQUIRE(codes && U && edge_index && grad_p && W1 && b1 && w2 && b2 && dv && hdz && dz && feat, SGS_EINVAL,
+    SGS_REQUIRE(codes && U && edge_index && grad_p && W1 && b1 && w2 && b2 && dv && hdz_part && dz && feat, SGS_EINVAL,
                 "sgs_edge_score_bwd_core: null pointer");
     SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_workspace_bytes(N, H, 0), SGS_EWORKSPACE, "sgs_edge_score_bwd_core: workspace too small");
     Carver cv(ws);
@@ -987,7 +1000,7 @@ int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64
     a.row_offset = edge_id_offset;
     a.H = static_cast<int>(H); a.WaT = WaT; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.drop_scale = 1.0f / (1.0f - p_drop); a.drop_thresh = dropout_thresh(p_drop); a.seed = seed; a.epoch = epoch_ptr(); a.site = site;
-    a.use_drop = p_drop > 0.f; a.gp = grad_p; a.dv = dv; a.hdz = hdz; a.dz = dz; a.feat = feat;
+    a.use_drop = p_drop > 0.f; a.gp = grad_p; a.dv = dv; a.hdz = hdz_part; a.dz = dz; a.feat = feat;
     return launch_score<true>(a, stream);
 }
 

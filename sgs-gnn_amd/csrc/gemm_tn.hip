@@ -52,9 +52,18 @@ __global__ void __launch_bounds__(64) gemm_tn_tile(const float* __restrict__ A, 
     }
 }
 
-__global__ void __launch_bounds__(256) gemm_tn_reduce(const float* __restrict__ slab, int64_t mn, int ksplit, float* __restrict__ C) {
+__global__ void __launch_bounds__(256) gemm_tn_reduce(const float* __restrict__ slab, int64_t mn, int ksplit, float* __restrict__ C,
+                                                      const float* __restrict__ cpart = nullptr, int M = 0, float* __restrict__ colsum = nullptr) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-    if (i >= mn) return;
+    if (i >= mn) {
+        const int64_t c = i - mn;                       // trailing threads: the column sums of A, slices in the same fixed order
+        if (colsum && c < M) {
+            float acc = 0.f;
+            for (int s = 0; s < ksplit; ++s) acc += cpart[static_cast<int64_t>(s) * M + c];
+            colsum[c] = acc;
+        }
+        return;
+    }
     float acc = 0.f;
     for (int s = 0; s < ksplit; ++s) acc += slab[static_cast<int64_t>(s) * mn + i];
     C[i] = acc;
@@ -72,7 +81,7 @@ constexpr int kTallK = 8192;
 constexpr int kTallU = 8;                    // k2-steps per register stage
 
 __global__ void __launch_bounds__(64) gemm_tn_tall_tile(const float* __restrict__ A, const float* __restrict__ B, int64_t K, int M, int N,
-                                                       int ksplit, float* __restrict__ slab) {
+                                                       int ksplit, float* __restrict__ slab, float* __restrict__ cpart) {
     const int lane = threadIdx.x, kh = lane >> 5, l31 = lane & 31;
     const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 64, s = blockIdx.z;
     const int ia = m0 + 4 * l31, jb = n0 + 2 * l31;
@@ -88,6 +97,10 @@ __global__ void __launch_bounds__(64) gemm_tn_tall_tile(const float* __restrict_
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float2 z2 = make_float2(0.f, 0.f);
+    // optional by-product: the column sums of A (the bias gradient d b1 = colsum(dv) when A = dv): the first N-tile's
+    // waves already stream every row of their 128 columns, so the sums cost four adds per k2-step
+    const bool want_cs = cpart != nullptr && blockIdx.y == 0;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
     auto load = [&](int64_t k, float4 (&a)[kTallU], float2 (&b)[kTallU]) {
 #pragma unroll
         for (int u = 0; u < kTallU; ++u) {
@@ -102,6 +115,7 @@ __global__ void __launch_bounds__(64) gemm_tn_tall_tile(const float* __restrict_
         for (int u = 0; u < kTallU; ++u) {
             const float av[4] = {a[u].x, a[u].y, a[u].z, a[u].w};
             const float bv[2] = {b[u].x, b[u].y};
+            if (want_cs) { cs[0] += av[0]; cs[1] += av[1]; cs[2] += av[2]; cs[3] += av[3]; }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -117,6 +131,11 @@ __global__ void __launch_bounds__(64) gemm_tn_tall_tile(const float* __restrict_
         mma(a0, b0);
         load(k + 4 * kTallU, a0, b0);
         mma(a1, b1);
+    }
+    if (want_cs) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) cs[t] += __shfl_xor(cs[t], 32, 64);          // even + odd rows of the slice
+        if (kh == 0 && aok) *reinterpret_cast<float4*>(cpart + static_cast<int64_t>(s) * M + ia) = make_float4(cs[0], cs[1], cs[2], cs[3]);
     }
     float* out = slab + static_cast<int64_t>(s) * M * N;
     // accumulator register r of tile (t, w): row m0 + 4 ((r & 3) + 8 (r >> 2) + 4 kh) + t, column n0 + 2 l31 + w
@@ -156,12 +175,29 @@ extern "C" {
 
 size_t sgs_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N) {
     if (K < 0 || M < 0 || N < 0) return 256;
-    return carve_bytes(static_cast<size_t>(pick_ksplit(K, M, N)) * M * N, 4) + 256;
+    const size_t ks = static_cast<size_t>(pick_ksplit(K, M, N));
+    return carve_bytes(ks * M * N, 4) + carve_bytes(ks * M, 4) + 256;       // split-K slabs + column-sum partials
 }
+
+static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, float* colsum_A, void* ws,
+                        size_t ws_bytes, hipStream_t stream);
 
 int sgs_gemm_tn(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, void* ws, size_t ws_bytes,
                 sgs_stream_t stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    return gemm_tn_impl(A, B, K, M, N, C, nullptr, ws, ws_bytes, static_cast<hipStream_t>(stream_));
+}
+
+int sgs_gemm_tn_can_colsum(int64_t K, int64_t M, int64_t N) { return use_tall(K, M, N) && pick_ksplit_tall(K, M, N) > 1 ? 1 : 0; }
+
+int sgs_gemm_tn_colsum(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, float* colsum_A, void* ws,
+                       size_t ws_bytes, sgs_stream_t stream_) {
+    SGS_REQUIRE(colsum_A && sgs_gemm_tn_can_colsum(K, M, N), SGS_EINVAL,
+                "sgs_gemm_tn_colsum: shape not served by the tall-K kernel (check sgs_gemm_tn_can_colsum)");
+    return gemm_tn_impl(A, B, K, M, N, C, colsum_A, ws, ws_bytes, static_cast<hipStream_t>(stream_));
+}
+
+static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, float* colsum_A, void* ws,
+                        size_t ws_bytes, hipStream_t stream) {
     SGS_REQUIRE(K >= 0 && M >= 0 && N >= 0 && M < (1 << 30) && N < (1 << 30), SGS_EINVAL, "sgs_gemm_tn: bad sizes");
     if (M == 0 || N == 0) return SGS_OK;
     SGS_REQUIRE(C && (K == 0 || (A && B)), SGS_EINVAL, "sgs_gemm_tn: null pointer");
@@ -169,14 +205,17 @@ int sgs_gemm_tn(const float* A, const float* B, int64_t K, int64_t M, int64_t N,
     const int ks = pick_ksplit(K, M, N);
     Carver cv(ws);
     float* slab = cv.take<float>(static_cast<size_t>(ks) * M * N);
+    float* cpart = cv.take<float>(static_cast<size_t>(ks) * M);
     float* dst = ks == 1 ? C : slab;
     if (use_tall(K, M, N))
         hipLaunchKernelGGL(gemm_tn_tall_tile, dim3(cdiv(M, 128), cdiv(N, 64), ks), dim3(64), 0, stream, A, B, K, static_cast<int>(M),
-                           static_cast<int>(N), ks, dst);
+                           static_cast<int>(N), ks, dst, colsum_A ? cpart : static_cast<float*>(nullptr));
     else
         hipLaunchKernelGGL(gemm_tn_tile, dim3(cdiv(M, 32), cdiv(N, 32), ks), dim3(64), 0, stream, A, B, K, static_cast<int>(M),
                            static_cast<int>(N), ks, dst);
-    if (ks > 1) hipLaunchKernelGGL(gemm_tn_reduce, dim3(cdiv(M * N, 256)), dim3(256), 0, stream, slab, M * N, ks, C);
+    if (ks > 1)
+        hipLaunchKernelGGL(gemm_tn_reduce, dim3(cdiv(M * N + (colsum_A ? M : 0), 256)), dim3(256), 0, stream, slab, M * N, ks, C,
+                           static_cast<const float*>(colsum_A ? cpart : nullptr), static_cast<int>(M), colsum_A);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

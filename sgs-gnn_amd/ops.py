@@ -421,7 +421,9 @@ class _EdgeScore(torch.autograd.Function):
             eid, graph, n = None, get_graph(edge_index, N), E
             gp_act = gp.contiguous()
         f32 = dict(dtype=torch.float32, device=dev)
-        dv, hdz, feat = torch.empty(n, H, **f32), torch.empty(n, H, **f32), torch.empty(n, H, **f32)
+        dv, feat = torch.empty(n, H, **f32), torch.empty(n, H, **f32)
+        tile = L.sgs_edge_score_bwd_tile()
+        hdz = torch.empty((n + tile - 1) // tile, H, **f32)          # per-tile column sums of dz * hidden (rows sum to d w2)
         dz = torch.empty(n, **f32)
         if n > 0:
             ws = workspace(L.sgs_edge_score_workspace_bytes(N, H, 0), dev)
@@ -436,9 +438,15 @@ class _EdgeScore(torch.autograd.Function):
         dW1 = torch.zeros_like(W1)
         dW1a = torch.empty(H, H, dtype=torch.float32, device=dev)
         wsg = workspace(L.sgs_gemm_tn_workspace_bytes(n, H, H), dev)
-        _lib.check(L.sgs_gemm_tn(_ptr(dv), _ptr(feat), n, H, H, _ptr(dW1a), wsg.data_ptr(), wsg.numel(), _stream()), "sgs_gemm_tn")
+        if L.sgs_gemm_tn_can_colsum(n, H, H):                  # d b1 = colsum(dv) as a by-product of the same pass over dv
+            db1 = torch.empty(H, dtype=torch.float32, device=dev)
+            _lib.check(L.sgs_gemm_tn_colsum(_ptr(dv), _ptr(feat), n, H, H, _ptr(dW1a), _ptr(db1), wsg.data_ptr(), wsg.numel(), _stream()),
+                       "sgs_gemm_tn_colsum")
+        else:
+            _lib.check(L.sgs_gemm_tn(_ptr(dv), _ptr(feat), n, H, H, _ptr(dW1a), wsg.data_ptr(), wsg.numel(), _stream()), "sgs_gemm_tn")
+            db1 = _colsum(dv)
         dW1[:, :H] = dW1a                                      # (W1b's half arrives through U)
-        db1, dw2 = _colsum(dv), _colsum(hdz)
+        dw2 = _colsum(hdz)
         db2 = _colsum(dz.view(n, 1)).reshape(1)
         dcodes = _endpoint_reduce(dfeat, dfeat, codes, graph, 1.0, 1.0, H)
         dU = _endpoint_reduce(dv, dv, None, graph, 1.0, -1.0, H)

@@ -162,3 +162,25 @@ def test_gemm_tn_weight_gradient(pkg, K, M, N):
     assert err < (2e-6 if K < 8192 else 6e-6), err      # tall-K kernel: longer fp32 chains per slice
     refx = dY.double() @ W.detach().cpu().double()
     assert float((xd.grad.cpu().double() - refx).abs().max()) / (float(refx.abs().max()) + 1e-12) < 1e-5
+
+
+def test_gemm_tn_tall_with_column_sums(pkg):
+    """sgs_gemm_tn_colsum: dW = A^T B on the tall-K kernel with colsum(A) as a by-product (d b1 of the scorer backward)."""
+    L = pkg._lib.lib()
+    K, M, N = 30011, 256, 256
+    assert L.sgs_gemm_tn_can_colsum(K, M, N) == 1 and L.sgs_gemm_tn_can_colsum(1013, M, N) == 0
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(K, M, generator=g).to(DEV)
+    B = torch.randn(K, N, generator=g).to(DEV)
+    C = torch.empty(M, N, device=DEV)
+    cs = torch.empty(M, device=DEV)
+    ws = pkg.ops.workspace(L.sgs_gemm_tn_workspace_bytes(K, M, N), A.device)
+    pkg._lib.check(L.sgs_gemm_tn_colsum(A.data_ptr(), B.data_ptr(), K, M, N, C.data_ptr(), cs.data_ptr(), ws.data_ptr(), ws.numel(),
+                                        pkg.ops._stream()), "sgs_gemm_tn_colsum")
+    ref = A.double().t() @ B.double()
+    assert float((C.double() - ref).abs().max()) / float(ref.abs().max()) < 6e-6
+    refc = A.double().sum(0)
+    assert float((cs.double() - refc).abs().max()) / float(refc.abs().max()) < 2e-6
+    with pytest.raises(RuntimeError):
+        pkg._lib.check(L.sgs_gemm_tn_colsum(A.data_ptr(), B.data_ptr(), 100, M, N, C.data_ptr(), cs.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            pkg.ops._stream()), "sgs_gemm_tn_colsum")
