@@ -454,8 +454,8 @@ __global__ void __launch_bounds__(kThreads) small_reduce_sumexp(const float* __r
     if (threadIdx.x == 0) part_sum[blockIdx.x] = r;
 }
 
-constexpr int kKeyItems = 2;          // the key pass is ALU heavy (Philox + log + 2 divisions per edge): 512-edge workgroups spread a
-                                      // partition over ~3x more workgroups than the 2048-edge chunks of the reduction passes
+constexpr int kKeyItems = 8;          // edges per thread in the key pass.  (2, i.e. 512-edge workgroups, was tried to spread a partition over
+                                      // more CUs: 31 us instead of 19 -- the per-workgroup redundant reductions and the 2048-bin flush dominate)
 template <int MODE>
 __global__ void __launch_bounds__(kThreads) small_keys_hist0(const float* __restrict__ p, const float* __restrict__ prior,
                                                             const float* __restrict__ noise, uint64_t seed, uint64_t stream_id,
