@@ -126,8 +126,9 @@ def _dp_worker(rank, world, port, q_out, hipgraph=False):
         S.fix_seeds(100 + rank)                                   # different noise / dropout streams per rank
         torch.manual_seed(0)                                      # identical initial replicas
         m = S.GNNModel(12, 32, 5, dropout_prob=0.3, edge_mlp_type="GCN").to(DEV)
-        opt_gnn = torch.optim.Adam([p for n, p in m.named_parameters() if "gcn" in n], lr=1e-2)
-        opt_edge = torch.optim.Adam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-2)
+        Adam = S.FusedAdam if hipgraph else torch.optim.Adam      # graph mode as bench.py runs it: FusedAdam, stepped eagerly after the all-reduce
+        opt_gnn = Adam([p for n, p in m.named_parameters() if "gcn" in n], lr=1e-2)
+        opt_edge = Adam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-2)
         opt_all = torch.optim.Adam(m.parameters(), lr=1e-2)
         # rank-specific partitions, one of them too small to be sampled (E <= q): exercises every sync branch
         sizes = [6000, 900, 5000] if rank == 0 else [5500, 7000, 800]
