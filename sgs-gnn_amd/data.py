@@ -86,3 +86,89 @@ def reddit_partition_stream(num_parts: int = 230, seed: int = 42, nfeat: int = 6
         E = int(lo + (hi - lo) * float(torch.rand(1, generator=g)))
         out.append(synthetic_graph(n, E, nfeat, ncls, seed * 1000 + i, device=device))
     return out
+
+
+class ResidentPartitions:
+    """All partitions of one graph resident in HBM: the device-side counterpart of the reference's
+    `ClusterData(data, num_parts)` + `ClusterLoader(cluster_data, batch_size=1, shuffle=True)` (main.py:63-65; SURVEY.md
+    section 8f item 2).  The reference re-slices every batch on the CPU and copies it to the GPU each time it is visited;
+    here the partitioning is applied ONCE on the device (METIS itself stays a host preprocessing step: pass its node ->
+    partition vector as `part_id`) and iteration yields `Batch` objects whose tensors never move again -- which is also
+    what the HIP-graph replay of the step needs (captures are keyed on the batch tensors' addresses).
+
+    Semantics follow ClusterData: partition p holds the nodes with part_id == p (in ascending original id), the edges with
+    BOTH endpoints in p (relabelled, row-sorted), the node attributes x / y / masks, and the edge attribute `prob` sliced
+    from the full graph's prior (`prior="global"`, what the reference does: add_degree runs before partitioning,
+    datasets.py:141-156) or recomputed on the partition (`prior="local"`)."""
+
+    def __init__(self, x, edge_index, y, train_mask, val_mask, test_mask, part_id, num_parts=None, device="cuda:0", prior="global",
+                 prob=None, shuffle=False, seed=0):
+        dev = torch.device(device)
+        part_id = part_id.to(dev).to(torch.int64)
+        N = x.shape[0]
+        if part_id.numel() != N:
+            raise ValueError("part_id must have one entry per node")
+        P = int(num_parts) if num_parts is not None else int(part_id.max()) + 1
+        ei = edge_index.to(dev)
+        E = ei.shape[1]
+        if prob is None and prior == "global":
+            if dev.type == "cuda":
+                from . import ops
+                # the device op wants a row-sorted edge list (CSR build); sort a copy and scatter the prior back
+                order = torch.argsort(ei[0] * N + ei[1])
+                p_sorted = ops.degree_prior(ei[:, order].contiguous(), N)
+                prob = torch.empty_like(p_sorted)
+                prob[order] = p_sorted
+            else:
+                prob = degree_prior(ei, N)
+        elif prob is not None:
+            prob = prob.to(dev)
+        # nodes grouped by partition (stable: ascending original id inside a partition)
+        perm = torch.argsort(part_id, stable=True)
+        counts = torch.bincount(part_id, minlength=P)
+        nptr = torch.zeros(P + 1, dtype=torch.int64, device=dev)
+        nptr[1:] = torch.cumsum(counts, 0)
+        new_id = torch.empty(N, dtype=torch.int64, device=dev)
+        new_id[perm] = torch.arange(N, device=dev)
+        # intra-partition edges, relabelled, sorted by (partition, new src, new dst)
+        ps, pd = part_id[ei[0]], part_id[ei[1]]
+        keep = ps == pd
+        src, dst, pe = new_id[ei[0][keep]], new_id[ei[1][keep]], ps[keep]
+        order = torch.argsort(src * N + dst)            # new ids are grouped by partition, so this sorts by (p, src, dst)
+        src, dst, pe = src[order], dst[order], pe[order]
+        eprob = prob[keep][order] if prob is not None else None
+        ecounts = torch.bincount(pe, minlength=P)
+        eptr = torch.zeros(P + 1, dtype=torch.int64, device=dev)
+        eptr[1:] = torch.cumsum(ecounts, 0)
+        xs, ys = x.to(dev)[perm], y.to(dev)[perm]
+        tm, vm, sm = train_mask.to(dev)[perm], val_mask.to(dev)[perm], test_mask.to(dev)[perm]
+        nptr_h, eptr_h = nptr.tolist(), eptr.tolist()    # one read-back at construction time
+        self.num_parts, self.perm, self.node_ptr, self.edge_ptr = P, perm, nptr, eptr
+        self.dropped_edges = int(E - int(keep.sum()))    # inter-partition edges (ClusterLoader with batch_size=1 drops them too)
+        self.batches = []
+        for p in range(P):
+            a, b, ea, eb = nptr_h[p], nptr_h[p + 1], eptr_h[p], eptr_h[p + 1]
+            lei = torch.stack([src[ea:eb] - a, dst[ea:eb] - a]).contiguous()
+            if eprob is not None:
+                bp = eprob[ea:eb].contiguous()
+            elif dev.type == "cuda" and eb > ea:
+                from . import ops
+                bp = ops.degree_prior(lei, b - a)
+            else:
+                bp = degree_prior(lei, b - a)
+            self.batches.append(Batch(x=xs[a:b].contiguous(), edge_index=lei, y=ys[a:b].contiguous(), train_mask=tm[a:b].contiguous(),
+                                      val_mask=vm[a:b].contiguous(), test_mask=sm[a:b].contiguous(), prob=bp, part=p,
+                                      node_ids=perm[a:b]))
+        self.shuffle = shuffle
+        self._gen = torch.Generator().manual_seed(seed)
+
+    def __len__(self):
+        return self.num_parts
+
+    def __getitem__(self, i):
+        return self.batches[i]
+
+    def __iter__(self):
+        order = torch.randperm(self.num_parts, generator=self._gen).tolist() if self.shuffle else range(self.num_parts)
+        for i in order:
+            yield self.batches[i]

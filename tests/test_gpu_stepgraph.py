@@ -189,3 +189,26 @@ def test_graph_mode_training_with_dropout_runs_and_learns(capturable):
     args_e = argparse.Namespace(degree_bias_coef=0.3, num_samples_eval=2)
     f1 = S.evaluate(args_e, m, bs, DEV, q=q, mode="learned")
     assert all(0.0 <= v <= 1.0 for v in f1)
+
+
+def test_graph_mode_with_gat_model_straight_through():
+    """Config 4 (GAT encoder, straight-through pipeline) through the replayed step: attention dropout draws from the RNG
+    epoch word too; parameter names follow main.py:100-109 ('GAT' goes to the GNN optimiser)."""
+    import sgs_gnn_amd as S
+    torch.manual_seed(5)
+    S.fix_seeds(5)
+    crit = torch.nn.CrossEntropyLoss()
+    bs = _batches(S, [5000, 900, 4000], n=150)
+    q = 1000
+    m = S.GATModel(24, 32, 5, dropout_prob=0.3, edge_mlp_type="GCN").to(DEV)
+    og = S.FusedAdam([p for n, p in m.named_parameters() if "GAT" in n or "gcn" in n], lr=1e-2)
+    oe = S.FusedAdam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-2)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    a = _args(sgs_hipgraph=True, pipeline="straight_through")
+    for ep in range(6):
+        loss, _, cond, tot = S.train(a, ep, 6, m, og, oe, None, crit, bs, q=q)
+        assert tot == 3 and loss == loss
+    for n, p in m.named_parameters():
+        assert torch.isfinite(p).all(), n
+    assert any(not torch.equal(p, before[n]) for n, p in m.named_parameters() if "GAT" in n)
+    assert len(m._sgs_stepgraphs.table) == 3
