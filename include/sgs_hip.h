@@ -376,6 +376,16 @@ int sgs_gemm_tn_colsum(const float* A, const float* B, int64_t K, int64_t M, int
                        size_t ws_bytes, sgs_stream_t stream);
 
 /* ----------------------------------------------------------------------------------
+ * Effective-resistance edge prior (datasets.py:159-173 add_ER; estimator: EffectiveResistanceWeights.ipynb cell 11 er_edge).
+ * weight[e] = max(0, sum_{i < walk_lengths} (X_is/deg s - X_it/deg t - Y_is/deg s + Y_it/deg t) / walks) with X / Y the
+ * numbers of `walks` uniform random walks of length i from s / t that end at s or t (reference: walk_lengths = 4, walks = 100).
+ * out_ptr / out_dst: CSR of the symmetric, coalesced edge list (sgs_graph_build); counter-based randomness keyed on
+ * (seed, edge, walk, step).  The host applies softmax(weight * E^-1/2) as add_ER does.
+ * ---------------------------------------------------------------------------------- */
+int sgs_er_weight(const int64_t* edge_index, int64_t E, int64_t N, const int32_t* out_ptr, const int32_t* out_dst, int walk_lengths,
+                  int walks, uint64_t seed, float* weight, sgs_stream_t stream);
+
+/* ----------------------------------------------------------------------------------
  * Optimiser (training_hybrid.py:22-27, 135-141: two torch.optim.Adam steps per batch).
  * One launch updates up to sgs_adam_max_tensors() tensors with torch.optim.Adam's rule (coupled weight decay, no amsgrad):
  *   desc_host [n_tensors][6] int64 in HOST memory, read during the call only (the descriptors travel by value in the

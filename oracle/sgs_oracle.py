@@ -470,3 +470,68 @@ def init_params(in_channels: int, hidden: int, num_classes: int, scorer: str = "
     P["gcn2.bias"] = (torch.rand(num_classes, generator=g, dtype=dtype) - 0.5) * 0.1
     P["gcn2.lin.weight"] = glorot(num_classes, hidden)
     return P
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Effective-resistance prior (datasets.py:159-173 add_ER; estimator EffectiveResistanceWeights.ipynb cell 11 `er_edge`).
+# The reference's estimator is Monte Carlo (python `random.choice` walks on a networkx graph), so it cannot be pinned bit
+# for bit: "parity unpinned".  Two restatements: the estimator itself with an explicit generator, and its exact
+# expectation (powers of the random-walk transition matrix) which any correct implementation must approach as r grows.
+def _neighbors(edge_index, N):
+    nb = [set() for _ in range(N)]
+    for s, d in edge_index.t().tolist():
+        nb[s].add(d)
+        nb[d].add(s)
+    return [sorted(x) for x in nb]
+
+
+def er_weight_monte_carlo(edge_index, N, l=4, r=100, generator=None, first=None):
+    """er_edge, walk by walk (small graphs only); `first`: only the first so many edges are estimated."""
+    nb = _neighbors(edge_index, N)
+    if first is not None:
+        edge_index = edge_index[:, :first]
+    g = generator or torch.Generator().manual_seed(0)
+
+    def walk(v, length):
+        for _ in range(length):
+            if not nb[v]:
+                continue
+            v = nb[v][int(torch.randint(0, len(nb[v]), (1,), generator=g))]
+        return v
+
+    out = torch.zeros(edge_index.shape[1])
+    for e, (s, t) in enumerate(edge_index.t().tolist()):
+        ds, dt = len(nb[s]), len(nb[t])
+        delta = 0.0
+        for i in range(l):
+            xis = xit = yis = yit = 0
+            for _ in range(r):
+                v = walk(s, i)
+                xis += v == s
+                xit += v == t
+            for _ in range(r):
+                v = walk(t, i)
+                yis += v == s
+                yit += v == t
+            delta += (xis / ds - xit / dt - yis / ds + yit / dt) / r
+        out[e] = max(0.0, delta)
+    return out
+
+
+def er_weight_expected(edge_index, N, l=4):
+    """E[delta] of er_edge: sum_i (P^i[s,s]/deg s - P^i[s,t]/deg t - P^i[t,s]/deg s + P^i[t,t]/deg t), clamped at 0."""
+    nb = _neighbors(edge_index, N)
+    P = torch.zeros(N, N, dtype=torch.float64)
+    for v in range(N):
+        if nb[v]:
+            P[v, nb[v]] = 1.0 / len(nb[v])
+        else:
+            P[v, v] = 1.0
+    deg = torch.tensor([max(len(x), 1) for x in nb], dtype=torch.float64)
+    s, t = edge_index[0], edge_index[1]
+    Pi = torch.eye(N, dtype=torch.float64)
+    delta = torch.zeros(edge_index.shape[1], dtype=torch.float64)
+    for _ in range(l):
+        delta += Pi[s, s] / deg[s] - Pi[s, t] / deg[t] - Pi[t, s] / deg[s] + Pi[t, t] / deg[t]
+        Pi = Pi @ P
+    return delta.clamp_min(0.0)

@@ -708,6 +708,20 @@ def degree_prior(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
     return torch.softmax(logits, dim=0)
 
 
+def er_prior(edge_index: torch.Tensor, num_nodes: int, seed: int = 0, walk_lengths: int = 4, walks: int = 100, raw: bool = False) -> torch.Tensor:
+    """`data.prob` of datasets.py:159-173 (add_ER) computed on the device: random-walk effective-resistance weights
+    (sgs_er_weight) then softmax(weight * E^-1/2).  `edge_index` must be symmetric and coalesced (what the reference's
+    to_networkx(to_undirected=True) walks on); raw=True returns the un-normalised weights."""
+    L = _lib.lib()
+    _need_gpu(edge_index)
+    g = get_graph(edge_index, num_nodes)
+    E = edge_index.shape[1]
+    w = torch.empty(E, dtype=torch.float32, device=edge_index.device)
+    _lib.check(L.sgs_er_weight(_ptr(g.edge_index), E, num_nodes, _ptr(g.out_ptr), _ptr(g.out_dst), int(walk_lengths), int(walks), int(seed),
+                               _ptr(w), _stream()), "sgs_er_weight")
+    return w if raw else torch.softmax(w * E ** -0.5, dim=0)
+
+
 # ------------------------------------------------------------------ one GCN layer as ONE autograd node
 class _GCNLayer(torch.autograd.Function):
     """Y = act(A_hat (x W^T) + bias): the node-level product (library GEMM) and the propagation (K5) in a single
