@@ -535,3 +535,28 @@ def er_weight_expected(edge_index, N, l=4):
         delta += Pi[s, s] / deg[s] - Pi[s, t] / deg[t] - Pi[t, s] / deg[s] + Pi[t, t] / deg[t]
         Pi = Pi @ P
     return delta.clamp_min(0.0)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# GIN / Cheb heads (model.py:165-184, 211-230).  PyG 2.3.1 layers restated from memory: parity unpinned.
+def gin_conv(x, edge_index, W0, b0, W1, b1, eps=0.0):
+    """GINConv(nn=MLP([a, b, b])): nn((1 + eps) x_i + sum_{j -> i} x_j), MLP = Linear -> ReLU -> Linear."""
+    agg = torch.zeros_like(x).index_add_(0, edge_index[1], x[edge_index[0]]) + (1.0 + eps) * x
+    return torch.relu(agg @ W0.t() + b0) @ W1.t() + b1
+
+
+def gin_forward(P, x, edge_index, keep=None, p=0.0, prefix="GIN.convs."):
+    """models.GIN(num_layers=2, act='relu', dropout=p): conv -> relu -> dropout -> conv."""
+    g = lambda i, k: P[f"{prefix}{i}.nn.lins.{k}"]
+    h = torch.relu(gin_conv(x, edge_index, g(0, "0.weight"), g(0, "0.bias"), g(0, "1.weight"), g(0, "1.bias")))
+    if keep is not None and p > 0:
+        h = h * keep / (1.0 - p)
+    return gin_conv(h, edge_index, g(1, "0.weight"), g(1, "0.bias"), g(1, "1.weight"), g(1, "1.bias"))
+
+
+def cheb_forward(P, x, keep=None, p=0.0):
+    """ChebConv(K=1): lins[0](x) + bias, twice with ReLU (+ dropout) between; the graph does not enter at K = 1."""
+    h = torch.relu(x @ P["gcn1.lins.0.weight"].t() + P["gcn1.bias"])
+    if keep is not None and p > 0:
+        h = h * keep / (1.0 - p)
+    return h @ P["gcn2.lins.0.weight"].t() + P["gcn2.bias"]

@@ -167,3 +167,108 @@ class GATModel(nn.Module):
 
     def forward(self, data, edge_index, edge_weight=None):
         return self.GAT(data.x, edge_index, edge_weight=edge_weight)
+
+
+# ------------------------------------------------------------------ GIN head (model.py:165-184)
+SITE_GIN = 48
+
+
+class _MLP2(nn.Module):
+    """torch_geometric.nn.MLP([a, b, b], act='relu', norm=None) as GIN.init_conv builds it (PyG 2.3.1, from memory):
+    Linear -> ReLU -> Linear; state_dict keys `lins.0.{weight,bias}`, `lins.1.{weight,bias}`."""
+
+    def __init__(self, a, b):
+        super().__init__()
+        self.lins = nn.ModuleList([nn.Linear(a, b), nn.Linear(b, b)])
+
+
+class GINConv(nn.Module):
+    """PyG GINConv(nn=MLP, eps=0, train_eps=False): out_i = nn((1 + eps) x_i + sum_{j -> i} x_j); `edge_weight` is not
+    supported by GIN (BasicGNN calls conv(x, edge_index)).  The first Linear commutes with the sum, so the aggregation runs
+    on the transformed features (hidden width instead of the input width): one SpMM with unit weights and diagonal 1 + eps."""
+
+    def __init__(self, in_channels, out_channels, eps=0.0):
+        super().__init__()
+        self.nn = _MLP2(in_channels, out_channels)
+        self.register_buffer("eps", torch.tensor([float(eps)]))      # state_dict key, as PyG (train_eps=False)
+        self._eps = float(eps)                                       # host copy: reading the buffer would synchronise
+
+    def forward(self, x, edge_index):
+        nm = ops.sum_norm(ops.get_graph(edge_index, x.shape[0]), 1.0 + self._eps)
+        l0, l1 = self.nn.lins
+        h = ops.gcn_propagate(ops.linear_nobias(x, l0.weight), nm, l0.bias, ops.ACT_RELU)
+        return ops.linear_nobias(h, l1.weight) + l1.bias
+
+
+class GIN(nn.Module):
+    """torch_geometric.nn.models.GIN(in, hidden, num_layers=2, out, dropout, act='relu'): conv -> relu -> dropout -> conv."""
+
+    def __init__(self, in_channels, hidden_channels, num_layers, out_channels, dropout=0.0, act='relu'):
+        super().__init__()
+        if num_layers != 2 or act != 'relu':
+            raise NotImplementedError("the reference instantiates GIN(num_layers=2, act='relu')")
+        self.dropout = dropout
+        self.convs = nn.ModuleList([GINConv(in_channels, hidden_channels), GINConv(hidden_channels, out_channels)])
+
+    def forward(self, x, edge_index, edge_weight=None):
+        h = F.relu(self.convs[0](x, edge_index))
+        p = self.dropout if self.training else 0.0
+        if p > 0:
+            keep = ops.dropout_keep(_DropoutClock.next_seed(), SITE_GIN, h.shape[0], h.shape[1], p, h.device)
+            h = h * keep / (1.0 - p)
+        return self.convs[1](h, edge_index)
+
+
+class GINModel(nn.Module):
+    """model.py:165-184."""
+
+    def __init__(self, in_channels, hidden_dim, num_classes, dropout_prob=0.3, edge_mlp_type='MLP'):
+        super().__init__()
+        from .scorer import get_edge_mlp
+        self.edge_prob_mlp = get_edge_mlp(in_channels, hidden_dim, dropout_prob, edge_mlp_type)
+        self.dropout_prob = dropout_prob
+        self.GIN = GIN(in_channels=in_channels, hidden_channels=hidden_dim, num_layers=2, out_channels=num_classes,
+                       dropout=dropout_prob, act='relu')
+
+    def forward(self, data, edge_index, edge_weight=None):
+        return self.GIN(data.x, edge_index, edge_weight=edge_weight)
+
+
+# ------------------------------------------------------------------ Chebyshev head (model.py:211-230)
+class ChebConv(nn.Module):
+    """PyG ChebConv(in, out, K=1, normalization='sym') as the reference instantiates it.  With K = 1 only T_0(L) x = x is
+    used: out = lins[0](x) + bias -- the Laplacian PyG normalises is never applied (so edge_index / edge_weight do not
+    influence the output; kept in the signature).  Keys: `lins.0.weight`, `bias`."""
+
+    def __init__(self, in_channels, out_channels, K=1, normalization='sym'):
+        super().__init__()
+        if K != 1:
+            raise NotImplementedError("the reference instantiates ChebConv(K=1)")
+        self.lins = nn.ModuleList([nn.Linear(in_channels, out_channels, bias=False)])
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        a = math.sqrt(6.0 / (in_channels + out_channels))            # glorot, as PyG's Linear(weight_initializer='glorot')
+        nn.init.uniform_(self.lins[0].weight, -a, a)
+
+    def forward(self, x, edge_index=None, edge_weight=None):
+        return ops.linear_nobias(x, self.lins[0].weight) + self.bias
+
+
+class ChebModel(nn.Module):
+    """model.py:211-230."""
+
+    def __init__(self, in_channels, hidden_dim, num_classes, dropout_prob=0.3, edge_mlp_type='MLP'):
+        super().__init__()
+        from .scorer import get_edge_mlp
+        self.edge_prob_mlp = get_edge_mlp(in_channels, hidden_dim, dropout_prob, edge_mlp_type)
+        self.dropout_prob = dropout_prob
+        self.gcn1 = ChebConv(in_channels, hidden_dim, K=1, normalization='sym')
+        self.dropout = nn.Dropout(dropout_prob)
+        self.gcn2 = ChebConv(hidden_dim, num_classes, K=1, normalization='sym')
+
+    def forward(self, data, edge_index, edge_weight=None):
+        h = F.relu(self.gcn1(data.x, edge_index, edge_weight))
+        p = self.dropout.p if self.training else 0.0
+        if p > 0:
+            keep = ops.dropout_keep(_DropoutClock.next_seed(), SITE_GNN, h.shape[0], h.shape[1], p, h.device)
+            h = h * keep / (1.0 - p)
+        return self.gcn2(h, edge_index, edge_weight)

@@ -696,6 +696,22 @@ def mean_norm(graph: Graph) -> Norm:
     return nm
 
 
+def sum_norm(graph: Graph, diag: float = 1.0) -> Norm:
+    """Norm-like object for GINConv's sum aggregation: unit edge weights and `diag` = 1 + eps on the node itself."""
+    nm = getattr(graph, "_norm_sum", None)
+    if nm is not None and nm[0] == diag:
+        return nm[1]
+    dev = graph.edge_index.device
+    nm = Norm()
+    nm.graph, nm.w, nm.handle, nm.dis, nm.loopw = graph, None, None, None, None
+    ne = max(graph.n_edges, 1)
+    nm.what_in = torch.ones(ne, dtype=torch.float32, device=dev)
+    nm.what_out = nm.what_in
+    nm.what_loop = torch.full((max(graph.N, 1),), float(diag), dtype=torch.float32, device=dev)
+    graph._norm_sum = (diag, nm)
+    return nm
+
+
 def degree_prior(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
     """`data.prob` of datasets.py:141-156 (add_degree) computed on the device."""
     L = _lib.lib()
