@@ -388,10 +388,12 @@ int sgs_er_weight(const int64_t* edge_index, int64_t E, int64_t N, const int32_t
 /* ----------------------------------------------------------------------------------
  * Optimiser (training_hybrid.py:22-27, 135-141: two torch.optim.Adam steps per batch).
  * One launch updates up to sgs_adam_max_tensors() tensors with torch.optim.Adam's rule (coupled weight decay, no amsgrad):
- *   desc_host [n_tensors][6] int64 in HOST memory, read during the call only (the descriptors travel by value in the
- *             kernel arguments): {param, grad, exp_avg, exp_avg_sq, numel, step}; the five pointers are DEVICE addresses;
+ *   desc_host [n_tensors][7] int64 in HOST memory, read during the call only (the descriptors travel by value in the
+ *             kernel arguments): {param, grad, exp_avg, exp_avg_sq, numel, step, gate}; the pointers are DEVICE addresses;
  *             `step` is that tensor's float counter of completed steps (one per parameter, as torch), read and then
- *             incremented by the kernel, so the call is capturable into a HIP graph
+ *             incremented by the kernel, so the call is capturable into a HIP graph; `gate` is 0 or the address of a
+ *             device float: while it reads 0 the tensor (and its counter) is left untouched (data-parallel training: the
+ *             scorer's tensors are skipped on steps where no rank took the learned branch, decided without a host round trip)
  *   ticket    device uint32, zero on first use (the kernel leaves it zero); one per concurrently running call
  * ---------------------------------------------------------------------------------- */
 int sgs_adam_max_tensors(void);

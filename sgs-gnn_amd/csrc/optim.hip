@@ -14,13 +14,14 @@ constexpr int kAT = 256;
 constexpr int kAChunk = 2048;
 constexpr int kAMax = 24;           // tensors per launch
 
-struct AdamDesc {                   // 6 x 64-bit words per tensor, same layout as the caller's int64 array
+struct AdamDesc {                   // 7 x 64-bit words per tensor, same layout as the caller's int64 array
     float* p;
     const float* g;
     float* m;
     float* v;
     int64_t n;
     float* step;                    // this tensor's completed steps (torch keeps one counter per parameter)
+    const float* gate;              // optional device predicate: the tensor is left untouched while *gate == 0
 };
 struct AdamArgs {
     AdamDesc d[kAMax];
@@ -37,6 +38,7 @@ __global__ void __launch_bounds__(kAT) adam_group(AdamArgs a) {
     while (static_cast<int>(blockIdx.x) >= a.chunk_end[ti]) ++ti;      // uniform; <= kAMax steps
     const int chunk = static_cast<int>(blockIdx.x) - (ti ? a.chunk_end[ti - 1] : 0);
     const AdamDesc d = a.d[ti];
+    const bool open = d.gate == nullptr || d.gate[0] != 0.f;   // data-parallel runs: "no rank took the learned branch" skips the scorer's tensors
     const float t = d.step[0] + 1.0f;                 // read by every workgroup before any of them can bump it (below)
     // bias corrections in double: beta^t for t up to millions
     const double bc1 = 1.0 - exp(static_cast<double>(t) * log(static_cast<double>(a.beta1)));
@@ -48,7 +50,7 @@ __global__ void __launch_bounds__(kAT) adam_group(AdamArgs a) {
 #pragma unroll
     for (int it = 0; it < kAChunk / kAT; ++it) {
         const int64_t i = base + static_cast<int64_t>(it) * kAT + threadIdx.x;
-        if (i < d.n) {
+        if (open && i < d.n) {
             float g = d.g[i];
             if (a.maximize) g = -g;
             const float p = d.p[i];
@@ -68,7 +70,10 @@ __global__ void __launch_bounds__(kAT) adam_group(AdamArgs a) {
     if (threadIdx.x == 0) s_last = (atomicAdd(a.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
     __syncthreads();
     if (s_last) {
-        if (static_cast<int>(threadIdx.x) < a.n_tensors) a.d[threadIdx.x].step[0] += 1.0f;
+        if (static_cast<int>(threadIdx.x) < a.n_tensors) {
+            const AdamDesc& dd = a.d[threadIdx.x];
+            if (dd.gate == nullptr || dd.gate[0] != 0.f) dd.step[0] += 1.0f;
+        }
         if (threadIdx.x == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -93,13 +98,14 @@ int sgs_adam_step(const int64_t* desc_host, int64_t n_tensors, float lr, float b
     int64_t total = 0;
     for (int i = 0; i < kAMax; ++i) {
         if (i < n_tensors) {
-            const int64_t* w = desc_host + 6 * i;
+            const int64_t* w = desc_host + 7 * i;
             a.d[i].p = reinterpret_cast<float*>(w[0]);
             a.d[i].g = reinterpret_cast<const float*>(w[1]);
             a.d[i].m = reinterpret_cast<float*>(w[2]);
             a.d[i].v = reinterpret_cast<float*>(w[3]);
             a.d[i].n = w[4];
             a.d[i].step = reinterpret_cast<float*>(w[5]);
+            a.d[i].gate = reinterpret_cast<const float*>(w[6]);
             SGS_REQUIRE(a.d[i].p && a.d[i].g && a.d[i].m && a.d[i].v && a.d[i].step && a.d[i].n >= 0, SGS_EINVAL,
                         "sgs_adam_step: bad descriptor %d", i);
             total += cdiv(a.d[i].n, kAChunk);

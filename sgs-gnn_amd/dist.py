@@ -42,8 +42,16 @@ class GradSync:
 
     def _ensure(self, device):
         if self.flat is None or self.flat.device != device:
-            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
-            self.views = [v.view_as(p) for v, p in zip(self.flat.split(self.sizes), self.params)]
+            # one extra word rides behind the gradients: the number of ranks whose gate chose "learned" (graph mode: the
+            # captured backward writes it, the same all-reduce sums it, the captured optimiser steps read it on the device)
+            self.flat = torch.zeros(self.numel + 1, dtype=torch.float32, device=device)
+            self.views = [v.view_as(p) for v, p in zip(self.flat[:self.numel].split(self.sizes), self.params)]
+            self.flag = self.flat[self.numel:self.numel + 1]
+
+    def all_reduce_bucket(self) -> None:
+        """Graph mode: the gradients (and the flag word) were written into the bucket by a replayed backward graph; sum over
+        ranks.  The division by the world size and the optimiser steps are replayed from their own graph afterwards."""
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
 
     def any_learned(self, learned_local: torch.Tensor) -> torch.Tensor:
         """Device-side: sum over ranks of this rank's 0/1 gate outcome (enqueue BEFORE the gate read-back)."""

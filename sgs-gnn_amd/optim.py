@@ -34,8 +34,15 @@ class FusedAdam(torch.optim.Optimizer):
         return st
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, gate=None, gated=None):
+        """`gate`: optional device float tensor [1]; tensors in `gated` (a set of parameters; None = every tensor of this
+        optimiser) are left untouched while it reads 0 -- a device-side `if` with no host round trip."""
         loss = None
+        gate_ptr = 0
+        if gate is not None:
+            if not gate.is_cuda or gate.dtype != torch.float32 or gate.numel() != 1:
+                raise RuntimeError("FusedAdam: gate must be one float32 device word")
+            gate_ptr = gate.data_ptr()
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
@@ -57,7 +64,7 @@ class FusedAdam(torch.optim.Optimizer):
                         raise RuntimeError("FusedAdam: parameters and gradients must be dense, contiguous float32 HIP tensors")
                     st = self._init_state(p)
                     words += [p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
-                              st["step"].data_ptr()]
+                              st["step"].data_ptr(), gate_ptr if (gated is None or p in gated) else 0]
                 key = (gi, lo)
                 tk = self._tickets.get(key)
                 if tk is None:

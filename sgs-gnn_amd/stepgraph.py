@@ -55,6 +55,29 @@ def _opt_signature(optimizers):
     return tuple(sig)
 
 
+def _ensure_optimizer_state(opt) -> bool:
+    """Optimiser state must exist BEFORE a step is captured: state created inside a capture (zeros for the moments, the step
+    counter) would be re-created -- i.e. reset -- by every replay.  Returns False for optimisers this module cannot prepare."""
+    from .optim import FusedAdam
+    if isinstance(opt, FusedAdam):
+        for grp in opt.param_groups:
+            for p in grp["params"]:
+                opt._init_state(p)
+        return True
+    if type(opt) is torch.optim.Adam:
+        for grp in opt.param_groups:
+            for p in grp["params"]:
+                st = opt.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)      # capturable layout
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    if grp.get("amsgrad", False):
+                        st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return True
+    return False
+
+
 def _batch_key(batch):
     return (batch.x.data_ptr(), batch.edge_index.data_ptr(), batch.y.data_ptr(), batch.train_mask.data_ptr(),
             batch.prob.data_ptr() if getattr(batch, "prob", None) is not None else 0, batch.edge_index.shape[1],
@@ -64,9 +87,14 @@ def _batch_key(batch):
 class StepGraphs:
     """Per-model registry of captured partition steps."""
 
-    def __init__(self, model, pipeline, args, criterion, q, use_checkpoint, optimizers=None):
+    def __init__(self, model, pipeline, args, criterion, q, use_checkpoint, optimizers=None, sync=None):
         self.model = model
         self.optimizers = optimizers      # (optimizer_edge_prob, optimizer_gnn) when their steps are captured too
+        # data-parallel graph mode (N > 1 ranks, FusedAdam optimisers): the backward graphs write the gradients straight into
+        # GradSync's flat bucket, the trainer all-reduces it, and ONE more graph (g3) averages and steps both optimisers with
+        # the "did any rank learn" word read on the device -- one collective and no host round trip per step besides the gate
+        self.sync = sync
+        self.g3 = None
         self.pipeline = pipeline
         self.args = args
         self.criterion = criterion
@@ -94,21 +122,27 @@ class StepGraphs:
                 bool(self.use_checkpoint), tuple(p.data_ptr() for p in self.params), _opt_signature(self.optimizers))
 
     @classmethod
-    def attach(cls, model, pipeline, args, criterion, q, use_checkpoint, optimizers=None):
+    def attach(cls, model, pipeline, args, criterion, q, use_checkpoint, optimizers=None, sync=None):
         """`optimizers` = (optimizer_edge_prob, optimizer_gnn): when both are built with `capturable=True` (and the
         run is single-process) their steps are recorded at the end of the backward graphs, so a replayed step
         needs no eager launch at all; otherwise the trainer steps them eagerly after each replay."""
-        if optimizers is not None and not all(_capturable(o) for o in optimizers):
+        if optimizers is not None and not (all(_capturable(o) for o in optimizers) and all(_ensure_optimizer_state(o) for o in optimizers)):
             optimizers = None
+        if sync is not None:
+            from .optim import FusedAdam
+            if optimizers is None or not all(isinstance(o, FusedAdam) for o in optimizers):
+                optimizers, sync = None, None              # N > 1 without FusedAdam: eager all-reduce + eager optimiser steps
         sg = getattr(model, "_sgs_stepgraphs", None)
-        fresh = cls(model, pipeline, args, criterion, q, use_checkpoint, optimizers) if sg is None else None
+        if sg is not None and (sg.sync is None) != (sync is None):
+            sg = None
+        fresh = cls(model, pipeline, args, criterion, q, use_checkpoint, optimizers, sync) if sg is None else None
         if sg is not None:
             sg.args, sg.criterion = args, criterion
             old_opts = sg.optimizers
             sg.optimizers = optimizers
             if ((sg.pipeline, sg.q, sg.use_checkpoint) != (pipeline, q, use_checkpoint) or sg._config_key() != sg.cfg
                     or (old_opts is None) != (optimizers is None)):
-                fresh = cls(model, pipeline, args, criterion, q, use_checkpoint, optimizers)   # settings changed: drop old captures
+                fresh = cls(model, pipeline, args, criterion, q, use_checkpoint, optimizers, sync)   # settings changed: drop old captures
         if fresh is not None:
             sg = model._sgs_stepgraphs = fresh
         ops.set_rng_epoch_buffer(sg.epoch_word)
@@ -125,6 +159,30 @@ class StepGraphs:
     def _clear_grads(self):
         for p in self.params:
             p.grad = None
+
+    @property
+    def dp(self) -> bool:
+        return self.sync is not None
+
+    def _bind_bucket(self):
+        """DP graph mode: every parameter's .grad is its view of the flat bucket, so a captured backward accumulates in place."""
+        self.sync._ensure(self.device)
+        for p, v in zip(self.sync.params, self.sync.views):
+            p.grad = v
+
+    def _capture_g3(self):
+        """flat /= world; optimizer_edge_prob.step() unless no rank learned; optimizer_gnn.step() with the scorer's tensors
+        skipped unless some rank learned -- all decided on the device from the all-reduced flag word."""
+        import torch.distributed as dist
+        sy, (oe, og) = self.sync, self.optimizers
+        self._bind_bucket()
+        scorer_params = {p for grp in oe.param_groups for p in grp["params"]}
+        self.g3 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g3, stream=self.stream):
+            sy.flat.div_(float(dist.get_world_size()))
+            oe.step(gate=sy.flag)
+            og.step(gate=sy.flag, gated=scorer_params)
+        self._clear_grads()
 
     def _capture(self, batch, key) -> _Captured:
         # The cyclic collector must not run inside a capture: it may finalise objects whose destructors call into
@@ -153,13 +211,19 @@ class StepGraphs:
         for mod in self.model.modules():               # no memoised x W^T from an eager step may leak into a capture
             if hasattr(mod, "_lin_cache"):
                 mod._lin_cache = None
+        if self.dp and self.g3 is None:
+            self._capture_g3()
         if not c.sampled:
+            if self.dp:
+                self._bind_bucket()
             with torch.cuda.graph(c.g1, stream=self.stream):
                 self.epoch_word.add_(1)
+                if self.dp:
+                    self.sync.flat.zero_()                         # gradients of this step + flag word (0: nobody learned here)
                 out = self.model(batch, batch.edge_index)
                 c.loss = _ce(self.criterion, out, batch)
                 c.loss.backward(gradient=self.one)
-                if self.optimizers is not None:
+                if self.optimizers is not None and not self.dp:
                     self.optimizers[1].step()                      # optimizer_gnn (training_hybrid.py:161)
                 self.loss_sum.add_(c.loss.detach())
             c.grads = self._grads()
@@ -180,10 +244,16 @@ class StepGraphs:
                       learned_out=st.learned_out.detach(),
                       random_out=None if st.random_out is None else st.random_out.detach())
         c.g2l = torch.cuda.CUDAGraph()
+        if self.dp:
+            self._bind_bucket()
         with torch.cuda.graph(c.g2l, stream=self.stream, **({"pool": pool} if pool is not None else {})):
+            if self.dp:
+                self.sync.flat.zero_()
             loss_l = learned_loss(a, self.criterion, st, batch)
             loss_l.backward(gradient=self.one, retain_graph=st.random_out is not None)
-            if self.optimizers is not None:
+            if self.dp:
+                self.sync.flag.fill_(1.0)                          # this rank's gate chose "learned"
+            elif self.optimizers is not None:
                 self.optimizers[0].step()                          # optimizer_edge_prob, then optimizer_gnn (:136-137)
                 self.optimizers[1].step()
             self.loss_sum.add_(loss_l.detach())
@@ -193,10 +263,14 @@ class StepGraphs:
         c.g2r = None
         if st.random_out is not None:
             c.g2r = torch.cuda.CUDAGraph()
+            if self.dp:
+                self._bind_bucket()
             with torch.cuda.graph(c.g2r, stream=self.stream, **({"pool": pool} if pool is not None else {})):
+                if self.dp:
+                    self.sync.flat.zero_()
                 loss_r = _ce(self.criterion, st.random_out, batch)
                 loss_r.backward(gradient=self.one)
-                if self.optimizers is not None:
+                if self.optimizers is not None and not self.dp:
                     self.optimizers[1].step()                      # optimizer_gnn only (:141)
                 self.loss_sum.add_(loss_r.detach())
             c.grads_r = self._grads()
@@ -248,7 +322,7 @@ class _ReplayHandle:
 
     def __init__(self, sg, c, seq0):
         self.sg, self.c, self.sampled, self.cbuf = sg, c, c.sampled, c.cbuf
-        self.opt_in_graph = sg.optimizers is not None      # the backward graphs end with the optimiser steps
+        self.opt_in_graph = sg.optimizers is not None      # the backward graphs (or, data-parallel, g3) hold the optimiser steps
         self.seq0 = seq0
         self.loss_on_device = True                         # the graphs add their loss to sg.loss_sum
 
@@ -267,15 +341,20 @@ class _ReplayHandle:
     def backward(self, learned):
         c, sg = self.c, self.sg
         if not c.sampled:                              # the single graph already ran forward + backward
-            sg._set_grads(c.grads)
-            return c.loss
-        if learned:
+            loss, grads = c.loss, c.grads
+        elif learned:
             c.g2l.replay()
-            sg._set_grads(c.grads_l)
-            return c.loss_l
-        c.g2r.replay()
-        sg._set_grads(c.grads_r)
-        return c.loss_r
+            loss, grads = c.loss_l, c.grads_l
+        else:
+            c.g2r.replay()
+            loss, grads = c.loss_r, c.grads_r
+        if sg.dp:
+            # gradients + flag word sit in the flat bucket: one all-reduce, then the shared graph that averages and steps
+            sg.sync.all_reduce_bucket()
+            sg.g3.replay()
+        else:
+            sg._set_grads(grads)
+        return loss
 
 
 class _EagerHandle:

@@ -157,7 +157,7 @@ def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edg
     if getattr(args, "sgs_hipgraph", False) and mode == 'learned' and not noise and trace is None and _fused_ce_ok(criterion):
         from .stepgraph import StepGraphs               # opt-in: replay captured HIP graphs of each partition's step
         graphs = StepGraphs.attach(model, pipeline, args, criterion, q, use_checkpoint,
-                                   optimizers=(optimizer_edge_prob, optimizer_gnn) if sync is None else None)
+                                   optimizers=(optimizer_edge_prob, optimizer_gnn), sync=sync)
 
     try:
         return _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, optimizer,
@@ -188,6 +188,10 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
             # `h` (stepgraph.py, opt-in): the same segments replayed from captured HIP graphs instead of launched one by one
             h = graphs.forward(batch) if graphs is not None else None
             eager_opt = h is None or not h.opt_in_graph       # capturable optimisers are stepped inside the backward graph
+            # N > 1 with FusedAdam: a replayed step all-reduces the gradient bucket and replays the optimiser graph inside
+            # h.backward(); the "any rank learned" word travels in that bucket and is read on the device
+            fused_dp = h is not None and graphs.dp and h.loss_on_device
+            esync = sync if not fused_dp else None            # the eager collectives below are for every other case
             sampled = h.sampled if h is not None else batch.edge_index.shape[1] > q
             if sampled:
                 st = sampled_forward(pipeline, args, model, batch, q, use_checkpoint, noise) if h is None else None
@@ -196,22 +200,22 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
                 update_edge_mlp = True
                 counts = None
                 any_learned = False
-                if args.conditional and h is not None and sync is None:
+                if args.conditional and h is not None and esync is None:
                     counts = h.gate_counts() + [0]                                 # replay: polled from pinned host memory
                     counts = [counts[0:2], counts[2:4]]
                     update_edge_mlp = counts[0][0] > counts[1][0]
                 elif args.conditional:
                     cbuf = st.cbuf if h is None else h.cbuf
-                    if sync is not None:            # N > 1: does ANY rank's gate choose "learned"? (device-side, no extra sync)
-                        cbuf[4:5] = sync.any_learned((cbuf[0:1] > cbuf[2:3]).to(torch.int32))
+                    if esync is not None:           # N > 1: does ANY rank's gate choose "learned"? (device-side, no extra sync)
+                        cbuf[4:5] = esync.any_learned((cbuf[0:1] > cbuf[2:3]).to(torch.int32))
                     counts = cbuf.tolist()                                         # the step's one host read-back
-                    any_learned = sync is not None and counts[4] > 0
+                    any_learned = esync is not None and counts[4] > 0
                     counts = [counts[0:2], counts[2:4]]
                     # learned_f1 > random_f1 with f1 = correct / n_train on both sides (utils.py:163-169)
                     update_edge_mlp = counts[0][0] > counts[1][0]
 
-                if sync is not None and not args.conditional:
-                    sync.any_learned(torch.ones(1, dtype=torch.int32, device=batch.x.device))   # keep the collective in lock-step
+                if esync is not None and not args.conditional:
+                    esync.any_learned(torch.ones(1, dtype=torch.int32, device=batch.x.device))   # keep the collective in lock-step
                 if update_edge_mlp:
                     condtional_update += 1
                     if h is None:
@@ -219,8 +223,8 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
                         loss.backward()
                     else:
                         loss = h.backward(True)
-                    if sync is not None:
-                        sync.sync()
+                    if esync is not None:
+                        esync.sync()
                     if eager_opt:
                         optimizer_edge_prob.step()
                         optimizer_gnn.step()
@@ -230,8 +234,8 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
                         loss.backward()
                     else:
                         loss = h.backward(False)
-                    if sync is not None:
-                        sync.sync(all_random=not any_learned)
+                    if esync is not None:
+                        esync.sync(all_random=not any_learned)
                         if any_learned:
                             optimizer_edge_prob.step()      # another rank's gate chose "learned"
                     if eager_opt:
@@ -249,12 +253,12 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
                     loss.backward()
                 else:
                     loss = h.backward(None)
-                if sync is not None:
+                if esync is not None:
                     # every rank is in lock-step on the partition stream, so ranks whose partition is small
                     # (no sampling, no gate) still join the flag all-reduce and the gradient all-reduce
-                    flag = sync.any_learned(torch.zeros(1, dtype=torch.int32, device=batch.x.device))
+                    flag = esync.any_learned(torch.zeros(1, dtype=torch.int32, device=batch.x.device))
                     some_learned = int(flag.item()) > 0
-                    sync.sync(all_random=not some_learned)
+                    esync.sync(all_random=not some_learned)
                     if some_learned:
                         optimizer_edge_prob.step()
                 if eager_opt:

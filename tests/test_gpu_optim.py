@@ -73,3 +73,26 @@ def test_fused_adam_rejects_cpu_tensors():
     p.grad = torch.ones(3)
     with pytest.raises(RuntimeError):
         S.FusedAdam([p]).step()
+
+
+def test_fused_adam_device_gate():
+    """gate == 0 leaves the gated tensors and their step counters untouched; other tensors step; gate != 0 steps all."""
+    import sgs_gnn_amd as S
+    pa, pb = _params(4, [(50, 7), (300,)]), _params(4, [(50, 7), (300,)])
+    oa, ob = torch.optim.Adam(pa, lr=1e-2), S.FusedAdam(pb, lr=1e-2)
+    gate = torch.zeros(1, device=DEV)
+    g = torch.Generator().manual_seed(9)
+    for it in range(6):
+        grads = [torch.randn(a.shape, generator=g).to(DEV) for a in pa]
+        open_ = it % 2 == 0
+        gate.fill_(2.0 if open_ else 0.0)
+        for a, b, gr in zip(pa, pb, grads):
+            b.grad = gr.clone()
+        pa[0].grad = grads[0].clone() if open_ else None           # torch: the gated tensor simply has no gradient on closed steps
+        pa[1].grad = grads[1].clone()
+        oa.step()
+        ob.step(gate=gate, gated={pb[0]})
+    torch.cuda.synchronize()
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-7)
+    assert float(ob.state[pb[0]]["step"]) == 3.0 and float(ob.state[pb[1]]["step"]) == 6.0

@@ -175,6 +175,9 @@ def test_graph_mode_training_with_dropout_runs_and_learns(capturable):
     for ep in range(12):
         loss, _, cond, tot = S.train(a, ep, 12, m, og, oe, None, crit, bs, q=q)
         assert tot == 3 and 0 <= cond <= 2
+        if capturable:
+            # optimiser state exists before any step is captured (state created inside a capture would be reset by each replay)
+            assert all(len(o.state[p]) > 0 for o in (og, oe) for grp in o.param_groups for p in grp["params"])
         conds += cond
         losses.append(loss)
     assert all(torch.isfinite(torch.tensor(losses)))
