@@ -106,6 +106,10 @@ class StepGraphs:
         # warm-up visits and captures share one side stream: autograd stamps every node (AccumulateGrad included)
         # with the stream it was created on, and a capture must not meet nodes from the legacy default stream
         self.stream = torch.cuda.Stream(device=self.device)
+        # Second capture stream (SGS_SG_DEBUG=fork): the random encoder as a parallel branch beside the scorer.  Correct (tests pass
+        # with it), but on ROCm 7.2 a two-branch graph costs 133 us of host time per launch instead of 24 us and the GPU time of the
+        # segment does not drop (810 vs 790 us): the step got 5 % slower, so the capture stays single-stream.
+        self.side = torch.cuda.Stream(device=self.device)
         self.one = torch.ones((), dtype=torch.float32, device=self.device)      # root gradient: saves autograd's ones_like fill per backward
         self.loss_sum = torch.zeros((), dtype=torch.float32, device=self.device)  # replayed steps add their loss here (read once per epoch)
         # gate read-back of a replayed step without a copy-engine round trip: G1 ends by publishing the counts to pinned,
@@ -232,7 +236,8 @@ class StepGraphs:
             return c
         with torch.cuda.graph(c.g1, stream=self.stream):
             self.epoch_word.add_(1)
-            st = sampled_forward(self.pipeline, a, self.model, batch, self.q, self.use_checkpoint)
+            st = sampled_forward(self.pipeline, a, self.model, batch, self.q, self.use_checkpoint,
+                                 side_stream=self.side if _DEBUG == "fork" else None)   # measured: a forked capture is SLOWER here (below)
             if st.cbuf is not None:
                 ops.publish_to_host(st.cbuf, 4, self.epoch_word, self.host_gate)
         pool = c.g1.pool() if _DEBUG != "nopool" else None

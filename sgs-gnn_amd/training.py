@@ -53,10 +53,14 @@ class SampledForward:
                  "random_out", "cbuf")
 
 
-def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise=None) -> SampledForward:
+def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise=None, side_stream=None) -> SampledForward:
     """training_hybrid.py:44-101 (ST 41-90, TP 41-92) up to the gate's inputs: prior draw, pass-1 scores, learned
     draw, encoder over the learned graph, encoder over the random graph, the two correct-counts (device side).
-    No host read-back in here, so the whole segment can be captured into a HIP graph (stepgraph.py)."""
+    No host read-back in here, so the whole segment can be captured into a HIP graph (stepgraph.py).
+    `side_stream` (graph capture only): the encoder over the random graph depends on the prior draw alone, so it is issued
+    on a second stream right after that draw and joins before the learned encoder -- in the captured graph it becomes a
+    parallel branch beside the scorer instead of ~4 more dependent launches on the critical path.  (Kept as an option:
+    measured slower on ROCm 7.2, see stepgraph.py.)"""
     noise = noise or {}
     st = SampledForward()
     N = batch.x.shape[0]
@@ -66,6 +70,14 @@ def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise
     if args.conditional or args.sparse_edge_mlp:                      # K0: prior-only draw
         rs = draw_prior(batch.prob, batch.edge_index, q, noise=noise.get("prior"))
         st.rsei = rs.edge_index
+    st.random_out = None
+    forked = side_stream is not None and args.conditional and st.rsei is not None
+    if forked:
+        ops.gcn_norm(ops.get_graph(st.rsei, N), None)                 # CSR + unit normalisation of the random graph: shared, built before the fork
+        main_stream = torch.cuda.current_stream()
+        side_stream.wait_stream(main_stream)
+        with torch.cuda.stream(side_stream):
+            st.random_out = model(batch, st.rsei)
 
     # pass 1: score every edge (hybrid / ST with grad, two-pass without)
     if pipeline == "two_pass":
@@ -93,12 +105,14 @@ def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise
     else:
         # pass 3: re-score the sampled edges with grad; encoder over the learned graph
         st.edge_probs_for_loss = scorer(batch.x, smp.edge_index).squeeze()
+    if forked:
+        main_stream.wait_stream(side_stream)                          # join (also publishes the memoised x W^T of the GNN's first layer)
     st.learned_out = model(batch, smp.edge_index, st.edge_probs_for_loss)
 
-    st.random_out = None
     st.cbuf = None
     if args.conditional:
-        st.random_out = model(batch, st.rsei)
+        if st.random_out is None:
+            st.random_out = model(batch, st.rsei)
         st.cbuf = torch.zeros(5, dtype=torch.int32, device=st.learned_out.device)
         ops.masked_correct_pair(st.learned_out, st.random_out, batch.y, batch.train_mask, st.cbuf)
     return st
