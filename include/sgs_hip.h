@@ -288,6 +288,11 @@ int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, i
                         const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid, const int32_t* out_ptr,
                         const int32_t* out_dst, const int32_t* out_eid, float sign_out, float sign_in, float* out,
                         sgs_stream_t stream);
+/* Both endpoint reductions of the scorer backward in one pass (needs H % 4 == 0, N <= 65536; 16-byte aligned rows):
+ *   out_codes = reduce(dfeat, dfeat, T = codes, +1, +1)        out_U = reduce(dv, dv, NULL, +1, -1) */
+int sgs_endpoint_reduce_pair(const float* dfeat, const float* dv, const float* codes, int64_t N, int64_t H, int64_t nnz,
+                             const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid, const int32_t* out_ptr,
+                             const int32_t* out_dst, const int32_t* out_eid, float* out_codes, float* out_U, sgs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K6: gate and losses (training_hybrid.py:92-133, utils.py:163-169, 187-211), all on device.

@@ -833,6 +833,72 @@ __global__ void __launch_bounds__(64 * NW) endpoint_reduce_rowblock(const float*
     }
 }
 
+// The scorer backward's two endpoint reductions in ONE pass over the incident-edge lists of a node v:
+//   out_codes[v,:] = sum_k dfeat[e_k,:] * codes[other_k,:]          (both orientations, sign +)
+//   out_U[v,:]     = sum_{k in out-row} dv[e_k,:] - sum_{k in in-row} dv[e_k,:]
+// (U[s] enters the pre-activation with +, U[d] with -).  Same row walk, same fixed summation order as two calls of
+// endpoint_reduce_rowblock; the edge ids / other-endpoint ids are read once and three row gathers are in flight per entry.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) endpoint_reduce_pair_rowblock(const float* __restrict__ dfeat, const float* __restrict__ dv,
+                                                                        const float* __restrict__ codes, int64_t N, int64_t H,
+                                                                        const int* __restrict__ in_ptr, const int* __restrict__ in_src,
+                                                                        const int* __restrict__ in_eid, const int* __restrict__ out_ptr,
+                                                                        const int* __restrict__ out_dst, const int* __restrict__ out_eid,
+                                                                        float* __restrict__ out_codes, float* __restrict__ out_U) {
+    __shared__ float part[2][NW][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t v = blockIdx.x;
+    const int ob = out_ptr[v], no = out_ptr[v + 1] - ob;
+    const int ib = in_ptr[v], ni = in_ptr[v + 1] - ib;
+    const int total = no + ni;
+    for (int64_t cbase = 0; cbase < H; cbase += 256) {
+        const int64_t c0 = cbase + static_cast<int64_t>(lane) * 4;
+        float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c0 < H) {
+            for (int k0 = wave; k0 < total; k0 += 2 * NW) {
+                float m1[2][4], m2[2][4], t[2][4], sg[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int k = k0 + NW * u;
+                    sg[u] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { m1[u][j] = 0.f; m2[u][j] = 0.f; t[u][j] = 0.f; }
+                    if (k < total) {
+                        const bool isout = k < no;
+                        const int idx = isout ? ob + k : ib + (k - no);
+                        const int er = isout ? out_eid[idx] : in_eid[idx];
+                        const int cr = isout ? out_dst[idx] : in_src[idx];
+                        sg[u] = isout ? 1.f : -1.f;
+                        *reinterpret_cast<float4*>(m1[u]) = *reinterpret_cast<const float4*>(dfeat + static_cast<int64_t>(er) * H + c0);
+                        *reinterpret_cast<float4*>(m2[u]) = *reinterpret_cast<const float4*>(dv + static_cast<int64_t>(er) * H + c0);
+                        *reinterpret_cast<float4*>(t[u]) = *reinterpret_cast<const float4*>(codes + static_cast<int64_t>(cr) * H + c0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        a1[j] = fmaf(m1[u][j], t[u][j], a1[j]);
+                        a2[j] = fmaf(sg[u], m2[u][j], a2[j]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { part[0][wave][lane * 4 + j] = a1[j]; part[1][wave][lane * 4 + j] = a2[j]; }
+        __syncthreads();
+        for (int tt = threadIdx.x; tt < 512; tt += 64 * NW) {
+            const int which = tt >> 8, c = tt & 255;
+            if (cbase + c < H) {
+                float sum = 0.f;
+#pragma unroll
+                for (int g = 0; g < NW; g += 4) sum += (part[which][g][c] + part[which][g + 1][c]) + (part[which][g + 2][c] + part[which][g + 3][c]);
+                (which ? out_U : out_codes)[v * H + cbase + c] = sum;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 inline size_t score_smem_bytes(int NT) { return 2 * (static_cast<size_t>(kBK) * 32 * NT * 4 + kBK * kBM * 4) + 2 * kBM * 4 + 2 * kBM * 4; }
 
 template <bool BWD>
@@ -1040,6 +1106,24 @@ int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, i
         if (T) hipLaunchKernelGGL((endpoint_reduce<1, true>), grid, blk, 0, stream, M_out, M_in, T, N, H, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, sign_out, sign_in, out);
         else   hipLaunchKernelGGL((endpoint_reduce<1, false>), grid, blk, 0, stream, M_out, M_in, T, N, H, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, sign_out, sign_in, out);
     }
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_endpoint_reduce_pair(const float* dfeat, const float* dv, const float* codes, int64_t N, int64_t H, int64_t nnz, const int32_t* in_ptr,
+                             const int32_t* in_src, const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_dst,
+                             const int32_t* out_eid, float* out_codes, float* out_U, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && H >= 0 && H % 4 == 0 && N <= 65536, SGS_EINVAL, "sgs_endpoint_reduce_pair: needs H %% 4 == 0 and N <= 65536");
+    if (N == 0 || H == 0) return SGS_OK;
+    SGS_REQUIRE(dfeat && dv && codes && in_ptr && out_ptr && out_codes && out_U, SGS_EINVAL, "sgs_endpoint_reduce_pair: null pointer");
+    const dim3 grid(static_cast<unsigned>(N));
+    if (nnz >= 64 * N)
+        hipLaunchKernelGGL((endpoint_reduce_pair_rowblock<16>), grid, dim3(1024), 0, stream, dfeat, dv, codes, N, H, in_ptr, in_src, in_eid, out_ptr,
+                           out_dst, out_eid, out_codes, out_U);
+    else
+        hipLaunchKernelGGL((endpoint_reduce_pair_rowblock<4>), grid, dim3(256), 0, stream, dfeat, dv, codes, N, H, in_ptr, in_src, in_eid, out_ptr,
+                           out_dst, out_eid, out_codes, out_U);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

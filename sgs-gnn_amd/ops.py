@@ -448,8 +448,15 @@ class _EdgeScore(torch.autograd.Function):
         dW1[:, :H] = dW1a                                      # (W1b's half arrives through U)
         dw2 = _colsum(hdz)
         db2 = _colsum(dz.view(n, 1)).reshape(1)
-        dcodes = _endpoint_reduce(dfeat, dfeat, codes, graph, 1.0, 1.0, H)
-        dU = _endpoint_reduce(dv, dv, None, graph, 1.0, -1.0, H)
+        if H % 4 == 0 and N <= 65536:                          # both endpoint reductions in one pass over the incident-edge lists
+            dcodes = torch.empty(N, H, dtype=torch.float32, device=dev)
+            dU = torch.empty(N, H, dtype=torch.float32, device=dev)
+            _lib.check(L.sgs_endpoint_reduce_pair(_ptr(dfeat), _ptr(dv), _ptr(codes), N, H, graph.n_edges, _ptr(graph.in_ptr), _ptr(graph.in_src),
+                                                  _ptr(graph.in_eid), _ptr(graph.out_ptr), _ptr(graph.out_dst), _ptr(graph.out_eid),
+                                                  _ptr(dcodes), _ptr(dU), _stream()), "sgs_endpoint_reduce_pair")
+        else:
+            dcodes = _endpoint_reduce(dfeat, dfeat, codes, graph, 1.0, 1.0, H)
+            dU = _endpoint_reduce(dv, dv, None, graph, 1.0, -1.0, H)
         return dcodes, dU, dW1, db1, dw2, db2, None, None, None, None, None, None
 
 
@@ -555,7 +562,7 @@ class _EdgeReg(torch.autograd.Function):
         ctx.save_for_backward(w, logits, sei, y, mask_u8, out)
         ctx.graph, ctx.coef1, ctx.coef2 = graph, float(coef1), float(coef2)
         box.append(out)
-        return out[4].clone()
+        return out[4]              # 0-dim view of the saved [5] vector (no copy launch)
 
     @staticmethod
     def backward(ctx, g):
