@@ -463,7 +463,8 @@ __global__ void __launch_bounds__(kT, 3) edge_score_stream_kernel(ScoreArgs a, c
 // (64 x 128: 8 accumulators, 2 waves per SIMD) reuses every A value twice: 8 loads per 32 MFMAs, 130 TFLOP/s for the
 // bare loop.  Workgroup = 128 edges x all H hidden units: wave = (edge pair-group, hidden half).
 constexpr int kBM2 = 128;
-template <int NT>
+// BWD: the backward core on the same loop (recompute, then dv / feat / dz / per-64-edge-tile sums of dz * hidden).
+template <int NT, bool BWD>
 __global__ void __launch_bounds__(kT, 2) edge_score_stream64_kernel(ScoreArgs a, const float* __restrict__ Wp, const float* __restrict__ Ceo) {
     constexpr int H = 32 * NT;
     constexpr int NTW = NT / 2;
@@ -508,7 +509,18 @@ __global__ void __launch_bounds__(kT, 2) edge_score_stream64_kernel(ScoreArgs a,
 #pragma unroll
         for (int g = 0; g < 2; ++g) { x[g] = xp[g][j4]; y[g] = yp[g][j4]; }
     };
-    auto mma = [&](const float4 (&A)[NTW], const float4 (&x)[2], const float4 (&y)[2]) {
+    auto mma = [&](int j4, const float4 (&A)[NTW], const float4 (&x)[2], const float4 (&y)[2]) {
+        if (BWD && hh == 0) {
+            // feat[e, k] = x_s[k] x_d[k] for the weight gradient: this lane holds k = 8 j4 + 2 jj + kh (jj = 0..3); the two
+            // half-waves swap two values each so that every lane stores four CONSECUTIVE k of its edge as one 16-byte row piece
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float o0 = x[g].x * y[g].x, o1 = x[g].y * y[g].y, o2 = x[g].z * y[g].z, o3 = x[g].w * y[g].w;
+                const float v0 = __shfl_xor(kh ? o0 : o2, 32, 64), v1 = __shfl_xor(kh ? o1 : o3, 32, 64);
+                const float4 row = kh ? make_float4(v0, o2, v1, o3) : make_float4(o0, v0, o1, v1);
+                if (live[g]) *reinterpret_cast<float4*>(a.feat + (row0 + el[g]) * H + 8 * j4 + 4 * kh) = row;
+            }
+        }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
@@ -528,9 +540,9 @@ __global__ void __launch_bounds__(kT, 2) edge_score_stream64_kernel(ScoreArgs a,
 #pragma unroll 1
     for (int j4 = 0; j4 < NJ4; j4 += 2) {
         load(j4 + 1, A1, x1, y1);                    // NJ4 is even (H % 16 == 0)
-        mma(A0, x0, y0);
+        mma(j4, A0, x0, y0);
         if (j4 + 2 < NJ4) load(j4 + 2, A0, x0, y0);
-        mma(A1, x1, y1);
+        mma(j4 + 1, A1, x1, y1);
     }
 
     // ---- epilogue (as variant B, once per edge group): hidden unit hh*H/2 + 8 i + (j) + 4 kh for step i = 4 t + g4
@@ -569,7 +581,9 @@ __global__ void __launch_bounds__(kT, 2) edge_score_stream64_kernel(ScoreArgs a,
                     const uint32_t draw = (j & 1) ? (bits[j >> 1] >> 16) : (bits[j >> 1] & 0xFFFFu);
                     m = draw >= a.drop_thresh ? m * a.drop_scale : 0.f;
                 }
-                z = fmaf(w4[j], v * m, z);
+                const float hd = v * m;                              // dropout(relu(v))
+                z = fmaf(w4[j], hd, z);
+                if (BWD) acc[g][t][4 * g4 + j] = hd;                 // kept for the second epilogue pass
             }
         };
         Epi L0, L1;
@@ -589,12 +603,56 @@ __global__ void __launch_bounds__(kT, 2) edge_score_stream64_kernel(ScoreArgs a,
         if (kh == 0) zpart[hh][el[g]] = z;
     }
     __syncthreads();
-    if (hh == 0 && kh == 0) {
+    if (!BWD) {
+        if (hh == 0 && kh == 0) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            if (live[g]) {
-                const float zz = (zpart[0][el[g]] + zpart[1][el[g]]) + a.b2[0];
-                a.p_out[row0 + el[g]] = 1.0f / (1.0f + expf(-zz));
+            for (int g = 0; g < 2; ++g) {
+                if (live[g]) {
+                    const float zz = (zpart[0][el[g]] + zpart[1][el[g]]) + a.b2[0];
+                    a.p_out[row0 + el[g]] = 1.0f / (1.0f + expf(-zz));
+                }
+            }
+        }
+        return;
+    }
+    // ---- backward epilogue: dz = gp p (1-p);  dv = dz w2 relu' keep scale;  per-64-edge-tile sums of dz * hidden
+    float dzv[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const float zz = (zpart[0][el[g]] + zpart[1][el[g]]) + a.b2[0];
+        const float p = 1.0f / (1.0f + expf(-zz));
+        dzv[g] = live[g] ? a.gp[row0 + el[g]] * p * (1.0f - p) : 0.f;             // 0 on the padding rows of the last tile
+        if (live[g] && hh == 0 && kh == 0) a.dz[row0 + el[g]] = dzv[g];
+    }
+    // this wave's 64 edges are exactly one tile of sgs_edge_score_bwd_tile() rows: row 2 blockIdx + ep of hdz_part, its hidden half
+    const int64_t prow = 2 * static_cast<int64_t>(blockIdx.x) + ep;
+    const bool prow_ok = prow * 64 < a.n;
+    const float dscale = a.use_drop ? a.drop_scale : 1.f;
+#pragma unroll
+    for (int i = 0; i < 4 * NTW; ++i) {
+        if (8 * i < Hrt) {                           // always true: one basic block per step (register budget, as above)
+            const int t = i >> 2, g4 = i & 3;
+            const int hb = hh * (H / 2) + 8 * i + 4 * kh;
+            const float4 ww = *reinterpret_cast<const float4*>(w2p + 8 * i);
+            const float w4[4] = {ww.x, ww.y, ww.z, ww.w};
+            float hs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float dv4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float hd = acc[g][t][4 * g4 + j];
+                    dv4[j] = dzv[g] * w4[j] * (hd > 0.f ? dscale : 0.f);     // hd > 0 <=> v > 0 and kept
+                    hs[j] = fmaf(dzv[g], hd, hs[j]);
+                }
+                if (live[g]) *reinterpret_cast<float4*>(a.dv + (row0 + el[g]) * H + hb) = make_float4(dv4[0], dv4[1], dv4[2], dv4[3]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float sum = hs[j];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);   // the 32 lanes of this half-wave (equal kh)
+                if (l31 == 0 && prow_ok) a.hdz[prow * H + hb + j] = sum;
             }
         }
     }
@@ -957,8 +1015,10 @@ size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H, int64_t E) {
 // 0 = LDS-tiled kernel, 1 = register-streaming kernel, 2 = weight-stationary persistent kernel (forward, H % 64 == 0).
 // A/B switch for benchmarks.  Measured (MI355X, E = 351 194, H = 256, same process): 0 -> 95, 1 -> 100.7, 2 -> 99.5 TFLOP/s;
 // whole-step throughput is equal within noise, so the fastest kernel is the default.
+static int g_bwd_variant = -1;     // -1 automatic, 0 LDS-tiled backward core, 3 64-edge streaming core (tests / A-B)
 static int g_score_variant = -1;   // -1: automatic (3 when the launch fills the chip with 128-edge workgroups, else 1)
 void sgs_edge_score_set_variant(int v) { g_score_variant = v; }
+void sgs_edge_score_set_bwd_variant(int v) { g_bwd_variant = v; }
 int sgs_edge_score_bwd_tile(void) { return kBM; }
 
 int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
@@ -1019,9 +1079,9 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
                                static_cast<int>(H), WaT, n_w, codes, N, Ceo);
         }
         const dim3 grid(static_cast<unsigned>(cdiv(E, kBM2))), blk(kT);
-        if (H == 256)      hipLaunchKernelGGL((edge_score_stream64_kernel<8>), grid, blk, 0, stream, a, WaT, Ceo);
-        else if (H == 128) hipLaunchKernelGGL((edge_score_stream64_kernel<4>), grid, blk, 0, stream, a, WaT, Ceo);
-        else               hipLaunchKernelGGL((edge_score_stream64_kernel<2>), grid, blk, 0, stream, a, WaT, Ceo);
+        if (H == 256)      hipLaunchKernelGGL((edge_score_stream64_kernel<8, false>), grid, blk, 0, stream, a, WaT, Ceo);
+        else if (H == 128) hipLaunchKernelGGL((edge_score_stream64_kernel<4, false>), grid, blk, 0, stream, a, WaT, Ceo);
+        else               hipLaunchKernelGGL((edge_score_stream64_kernel<2, false>), grid, blk, 0, stream, a, WaT, Ceo);
         SGS_LAUNCH_OK();
         return SGS_OK;
     }
@@ -1060,13 +1120,31 @@ int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64
     SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_workspace_bytes(N, H, 0), SGS_EWORKSPACE, "sgs_edge_score_bwd_core: workspace too small");
     Carver cv(ws);
     float* WaT = cv.take<float>(static_cast<size_t>(H) * H);
-    hipLaunchKernelGGL(transpose_w1a, dim3(cdiv(H, 32), cdiv(H, 32)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);
+    float* Ceo = cv.take<float>(static_cast<size_t>(N) * H);
+    // 64-edge wave tile only when the active set gives the 512 resident 128-edge workgroups several rounds (>= 262 144 rows:
+    // straight-through / dense backward over all E); at q = 100 000 its 1.5 rounds measured slower than the LDS-tiled core
+    const bool stream64 = H % 64 == 0 && (g_bwd_variant == 3 || (g_bwd_variant < 0 && cdiv(n_active, kBM2) >= 2048));
+    if (stream64) {
+        const int n_w = static_cast<int>(cdiv(H * H, kT));
+        hipLaunchKernelGGL(pack_stream_operands, dim3(static_cast<unsigned>(n_w + cdiv(N * H, kT))), dim3(kT), 0, stream, W1,
+                           static_cast<int>(H), WaT, n_w, codes, N, Ceo);
+    } else {
+        hipLaunchKernelGGL(transpose_w1a, dim3(cdiv(H, 32), cdiv(H, 32)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);
+    }
     ScoreArgs a{};
     a.codes = codes; a.U = U; a.src = edge_index; a.dst = edge_index + E; a.active = active_eid; a.n = n_active;
     a.row_offset = edge_id_offset;
     a.H = static_cast<int>(H); a.WaT = WaT; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.drop_scale = 1.0f / (1.0f - p_drop); a.drop_thresh = dropout_thresh(p_drop); a.seed = seed; a.epoch = epoch_ptr(); a.site = site;
     a.use_drop = p_drop > 0.f; a.gp = grad_p; a.dv = dv; a.hdz = hdz_part; a.dz = dz; a.feat = feat;
+    if (stream64) {
+        const dim3 grid(static_cast<unsigned>(cdiv(n_active, kBM2))), blk(kT);
+        if (H == 256)      hipLaunchKernelGGL((edge_score_stream64_kernel<8, true>), grid, blk, 0, stream, a, WaT, Ceo);
+        else if (H == 128) hipLaunchKernelGGL((edge_score_stream64_kernel<4, true>), grid, blk, 0, stream, a, WaT, Ceo);
+        else               hipLaunchKernelGGL((edge_score_stream64_kernel<2, true>), grid, blk, 0, stream, a, WaT, Ceo);
+        SGS_LAUNCH_OK();
+        return SGS_OK;
+    }
     return launch_score<true>(a, stream);
 }
 

@@ -106,3 +106,42 @@ def test_all_forward_variants_match_oracle(ops, variant, N, H, E, p):
     finally:
         L.sgs_edge_score_set_variant(-1)
     assert float((pd.cpu().double() - po).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("H,p", [(256, 0.3), (128, 0.0)])
+def test_backward_core_stream64_matches_lds_tiled(ops, H, p):
+    """The backward core on the 64-edge streaming loop (automatic from 262 144 active rows; forced here) against the LDS-tiled core:
+    dv, feat, dz and the column sums of the per-tile dz * hidden partials."""
+    import sgs_gnn_amd as S
+    L = S._lib.lib()
+    N, E, n = 1013, 60000, 40003
+    g = torch.Generator().manual_seed(H)
+    codes = torch.relu(torch.randn(N, H, generator=g)).to(DEV)
+    ei = torch.randint(0, N, (2, E), generator=g).to(DEV)
+    eid = torch.sort(torch.randperm(E, generator=g)[:n]).values.to(DEV)
+    W1 = (torch.randn(H, 2 * H, generator=g) / (2 * H) ** 0.5).to(DEV)
+    b1, w2, b2 = (torch.randn(H, generator=g) * 0.1).to(DEV), (torch.randn(H, generator=g) / H ** 0.5).to(DEV), torch.zeros(1, device=DEV)
+    U = (codes @ W1[:, H:].t()).contiguous()
+    gp = torch.randn(n, generator=g).to(DEV)
+    tile = L.sgs_edge_score_bwd_tile()
+    outs = []
+    try:
+        for variant in (0, 3):
+            L.sgs_edge_score_set_bwd_variant(variant)
+            dv, feat = torch.full((n, H), float("nan"), device=DEV), torch.full((n, H), float("nan"), device=DEV)
+            hdz = torch.full(((n + tile - 1) // tile, H), float("nan"), device=DEV)
+            dz = torch.full((n,), float("nan"), device=DEV)
+            ws = ops.workspace(L.sgs_edge_score_workspace_bytes(N, H, 0), codes.device)
+            S._lib.check(L.sgs_edge_score_bwd_core(codes.data_ptr(), U.data_ptr(), N, H, ei.data_ptr(), E, 0, eid.data_ptr(), n, gp.data_ptr(),
+                                                   W1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), p, 5, 2, dv.data_ptr(), hdz.data_ptr(),
+                                                   dz.data_ptr(), feat.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()), "bwd_core")
+            torch.cuda.synchronize()
+            outs.append((dv.cpu(), feat.cpu(), dz.cpu(), hdz.sum(0).cpu()))
+    finally:
+        L.sgs_edge_score_set_bwd_variant(-1)
+    (dv0, f0, dz0, h0), (dv1, f1, dz1, h1) = outs
+    assert torch.isfinite(dv1).all() and torch.isfinite(f1).all() and torch.isfinite(dz1).all() and torch.isfinite(h1).all()
+    assert torch.equal(f0, f1)                                           # x_s * x_d: the same single product either way
+    torch.testing.assert_close(dz1, dz0, rtol=2e-4, atol=1e-6)
+    torch.testing.assert_close(dv1, dv0, rtol=2e-4, atol=1e-6)
+    torch.testing.assert_close(h1, h0, rtol=2e-4, atol=2e-4)
