@@ -1015,7 +1015,7 @@ size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H, int64_t E) {
 // 0 = LDS-tiled kernel, 1 = register-streaming kernel, 2 = weight-stationary persistent kernel (forward, H % 64 == 0).
 // A/B switch for benchmarks.  Measured (MI355X, E = 351 194, H = 256, same process): 0 -> 95, 1 -> 100.7, 2 -> 99.5 TFLOP/s;
 // whole-step throughput is equal within noise, so the fastest kernel is the default.
-static int g_bwd_variant = -1;     // -1 automatic, 0 LDS-tiled backward core, 3 64-edge streaming core (tests / A-B)
+static int g_bwd_variant = -1;     // -1 / 0: LDS-tiled backward core (default), 3: 64-edge streaming core (A/B only: slower)
 static int g_score_variant = -1;   // -1: automatic (3 when the launch fills the chip with 128-edge workgroups, else 1)
 void sgs_edge_score_set_variant(int v) { g_score_variant = v; }
 void sgs_edge_score_set_bwd_variant(int v) { g_bwd_variant = v; }
@@ -1121,9 +1121,11 @@ int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64
     Carver cv(ws);
     float* WaT = cv.take<float>(static_cast<size_t>(H) * H);
     float* Ceo = cv.take<float>(static_cast<size_t>(N) * H);
-    // 64-edge wave tile only when the active set gives the 512 resident 128-edge workgroups several rounds (>= 262 144 rows:
-    // straight-through / dense backward over all E); at q = 100 000 its 1.5 rounds measured slower than the LDS-tiled core
-    const bool stream64 = H % 64 == 0 && (g_bwd_variant == 3 || (g_bwd_variant < 0 && cdiv(n_active, kBM2) >= 2048));
+    // The 64-edge streaming loop is available for the backward core too (variant 3), but it is NOT the default: measured
+    // (tools/bwd_probe.py) 323 / 656 / 1092 us against 227 / 558 / 997 us for the LDS-tiled core at 100 k / 262 k / 500 k active
+    // rows.  The backward is bound by what it writes (dv and feat, 2 KB per row) and the tiled core produces the feature tile
+    // in LDS anyway, while the streaming loop has to rebuild row pieces from registers with cross-lane swaps.
+    const bool stream64 = H % 64 == 0 && g_bwd_variant == 3;
     if (stream64) {
         const int n_w = static_cast<int>(cdiv(H * H, kT));
         hipLaunchKernelGGL(pack_stream_operands, dim3(static_cast<unsigned>(n_w + cdiv(N * H, kT))), dim3(kT), 0, stream, W1,

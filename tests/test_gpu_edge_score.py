@@ -110,7 +110,7 @@ def test_all_forward_variants_match_oracle(ops, variant, N, H, E, p):
 
 @pytest.mark.parametrize("H,p", [(256, 0.3), (128, 0.0)])
 def test_backward_core_stream64_matches_lds_tiled(ops, H, p):
-    """The backward core on the 64-edge streaming loop (automatic from 262 144 active rows; forced here) against the LDS-tiled core:
+    """The backward core on the 64-edge streaming loop (an A/B option, forced here) against the LDS-tiled core:
     dv, feat, dz and the column sums of the per-tile dz * hidden partials."""
     import sgs_gnn_amd as S
     L = S._lib.lib()
