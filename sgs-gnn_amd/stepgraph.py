@@ -1,38 +1,43 @@
 """Opt-in HIP-graph replay of the per-partition training step (`args.sgs_hipgraph = True`).
 
-Why: at partition scale (n ~ 1e3 nodes, E <= 5e5 edges) one hybrid step is ~120 kernel launches of a few
-microseconds each, and the Python + launch time per step exceeds the GPU-busy time (DESIGN.md section 7).
+Why: at partition scale (n ~ 1e3 nodes, E <= 5e5 edges) one hybrid step is ~70-150 kernel launches of a few
+microseconds each, and the Python + launch time per step exceeds the GPU-busy time (DESIGN.md section 5a / 7).
 The C ABI never allocates or synchronises, so a step's device work is capturable as is.  Per partition
 (keyed on the batch's tensors) the step is recorded once into HIP graphs and replayed afterwards:
 
     E_b >  q :  G1 = epoch += 1; prior draw -> scores -> learned draw -> CSR build -> learned / random encoders ->
-                     the two correct-counts                          (training.sampled_forward)
-                host reads the 16-byte gate buffer (the step's one read-back, as in eager mode)
-                G2L = CE + reg1 + reg2 and backward of the learned branch   |   G2R = CE and backward of the random branch
+                     the two correct-counts -> publish them to pinned host memory   (training.sampled_forward)
+                the host polls the gate words (the step's one read-back; eager mode does a 20-byte copy instead)
+                G2L = CE + reg1 + reg2, backward of the learned branch   |   G2R = CE, backward of the random branch
     E_b <= q :  G  = epoch += 1; encoder on all edges, CE, backward
 
-The optimiser steps stay eager (they belong to the caller); after a replay `.grad` of every parameter is
-pointed at that graph's static gradient buffer (or None when the branch gives it no gradient - Adam must
-skip those, as in eager mode).
+Optimisers: `capturable` ones (sgs_gnn_amd.FusedAdam, or torch's with capturable=True) are recorded at the end of the
+backward graphs -- their state is created before any capture, a state tensor born inside a capture would be reset by
+every replay; others are stepped eagerly after the replay, with `.grad` of every parameter pointed at that graph's static
+gradient buffer (or None where the branch gives no gradient: Adam must skip those, as in eager mode).
+Data parallel (N > 1, FusedAdam): the backward graphs accumulate straight into GradSync's flat bucket (zeroed by the graph)
+and add one "this rank learned" word; the trainer issues ONE all-reduce and replays g3, a single shared graph that divides
+by the world size and steps both optimisers with the all-reduced word read on the device (FusedAdam's per-tensor gate).
 
 Randomness: seeds are launch arguments and therefore frozen at capture; every capture starts by
 incrementing the registered RNG epoch word (ops.set_rng_epoch_buffer) which all RNG-consuming kernels fold
 into their seed, so each replay draws fresh Exp(1) noise and dropout masks.  The random stream therefore
 differs from eager mode's (same distributions); parity tests run eager mode.
 
-First visit of a partition runs eagerly (warm-up: lazy library initialisation, CSR cache, workspace growth),
-the second visit captures (and replays), later visits only replay.
+First visit of a partition runs eagerly on the capture stream (warm-up: lazy code-object loads, CSR cache, workspace
+growth, BOTH backward branches), the second visit captures (and replays), later visits only replay.  The per-step loss
+is accumulated on the device (`loss_sum`) and read once per epoch.
 """
 from __future__ import annotations
+
+import gc
+import os
 
 import torch
 
 from . import ops
 
-
-import gc
-import os
-_DEBUG = os.environ.get("SGS_SG_DEBUG", "")
+_DEBUG = os.environ.get("SGS_SG_DEBUG", "")     # "fork": capture the random encoder on a second stream (measured slower)
 
 
 class _Captured:
@@ -240,7 +245,7 @@ class StepGraphs:
                                  side_stream=self.side if _DEBUG == "fork" else None)   # measured: a forked capture is SLOWER here (below)
             if st.cbuf is not None:
                 ops.publish_to_host(st.cbuf, 4, self.epoch_word, self.host_gate)
-        pool = c.g1.pool() if _DEBUG != "nopool" else None
+        pool = c.g1.pool()
         c.cbuf = st.cbuf
         # static views of the replay's own draws and outputs (private-pool memory is never reused after the
         # capture, so holding them costs nothing); tests recompute the step eagerly from these
@@ -251,7 +256,7 @@ class StepGraphs:
         c.g2l = torch.cuda.CUDAGraph()
         if self.dp:
             self._bind_bucket()
-        with torch.cuda.graph(c.g2l, stream=self.stream, **({"pool": pool} if pool is not None else {})):
+        with torch.cuda.graph(c.g2l, stream=self.stream, pool=pool):
             if self.dp:
                 self.sync.flat.zero_()
             loss_l = learned_loss(a, self.criterion, st, batch)
@@ -270,7 +275,7 @@ class StepGraphs:
             c.g2r = torch.cuda.CUDAGraph()
             if self.dp:
                 self._bind_bucket()
-            with torch.cuda.graph(c.g2r, stream=self.stream, **({"pool": pool} if pool is not None else {})):
+            with torch.cuda.graph(c.g2r, stream=self.stream, pool=pool):
                 if self.dp:
                     self.sync.flat.zero_()
                 loss_r = _ce(self.criterion, st.random_out, batch)
