@@ -100,6 +100,10 @@ class StepGraphs:
         # the "did any rank learn" word read on the device -- one collective and no host round trip per step besides the gate
         self.sync = sync
         self.g3 = None
+        # With a process group alive, other threads (the collective watchdog) issue runtime queries at any time; "global" capture
+        # mode would turn one of those into a capture error, so captures only police their own thread then.
+        import torch.distributed as dist
+        self.capture_mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
         self.pipeline = pipeline
         self.args = args
         self.criterion = criterion
@@ -187,7 +191,7 @@ class StepGraphs:
         self._bind_bucket()
         scorer_params = {p for grp in oe.param_groups for p in grp["params"]}
         self.g3 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g3, stream=self.stream):
+        with torch.cuda.graph(self.g3, stream=self.stream, capture_error_mode=self.capture_mode):
             sy.flat.div_(float(dist.get_world_size()))
             oe.step(gate=sy.flag)
             og.step(gate=sy.flag, gated=scorer_params)
@@ -225,7 +229,7 @@ class StepGraphs:
         if not c.sampled:
             if self.dp:
                 self._bind_bucket()
-            with torch.cuda.graph(c.g1, stream=self.stream):
+            with torch.cuda.graph(c.g1, stream=self.stream, capture_error_mode=self.capture_mode):
                 self.epoch_word.add_(1)
                 if self.dp:
                     self.sync.flat.zero_()                         # gradients of this step + flag word (0: nobody learned here)
@@ -239,7 +243,7 @@ class StepGraphs:
             c.loss = c.loss.detach()
             self._clear_grads()
             return c
-        with torch.cuda.graph(c.g1, stream=self.stream):
+        with torch.cuda.graph(c.g1, stream=self.stream, capture_error_mode=self.capture_mode):
             self.epoch_word.add_(1)
             st = sampled_forward(self.pipeline, a, self.model, batch, self.q, self.use_checkpoint,
                                  side_stream=self.side if _DEBUG == "fork" else None)   # measured: a forked capture is SLOWER here (below)
@@ -256,7 +260,7 @@ class StepGraphs:
         c.g2l = torch.cuda.CUDAGraph()
         if self.dp:
             self._bind_bucket()
-        with torch.cuda.graph(c.g2l, stream=self.stream, pool=pool):
+        with torch.cuda.graph(c.g2l, stream=self.stream, pool=pool, capture_error_mode=self.capture_mode):
             if self.dp:
                 self.sync.flat.zero_()
             loss_l = learned_loss(a, self.criterion, st, batch)
@@ -275,7 +279,7 @@ class StepGraphs:
             c.g2r = torch.cuda.CUDAGraph()
             if self.dp:
                 self._bind_bucket()
-            with torch.cuda.graph(c.g2r, stream=self.stream, pool=pool):
+            with torch.cuda.graph(c.g2r, stream=self.stream, pool=pool, capture_error_mode=self.capture_mode):
                 if self.dp:
                     self.sync.flat.zero_()
                 loss_r = _ce(self.criterion, st.random_out, batch)
