@@ -18,6 +18,7 @@ with contextlib.redirect_stdout(io.StringIO()):
     for ep in range(3):
         S.train(args, ep, 10, model, og, oe, oa, crit, pool, q=B.Q)
 sg = model._sgs_stepgraphs
+print(json.dumps({"partitions_captured": len(sg.table), "hbm_allocated_GiB": round(torch.cuda.memory_allocated() / 2**30, 2), "hbm_reserved_GiB": round(torch.cuda.memory_reserved() / 2**30, 2)}))
 S.ops.set_rng_epoch_buffer(sg.epoch_word)
 
 def t(g, reps=20):
