@@ -155,6 +155,17 @@ int sgs_graph_build(const int64_t* edge_index, int64_t n_edges, int64_t N, int32
                     int32_t* in_eid, int32_t* out_ptr, int32_t* out_dst, int32_t* out_eid, int32_t* loop_eid,
                     void* ws, size_t ws_bytes, sgs_stream_t stream);
 
+/* CSR of a sampled subgraph from its PARENT's CSR (sgs_graph_build of the partition, built once and cached): the draw keeps
+ * a subset of the parent's edges in their original order, so the child rows are the parent rows with the unselected entries
+ * squeezed out and edge ids renumbered by rank in `sampled_eid` (ascending parent edge ids, as sgs_sample_topq emits them):
+ * no atomics, no per-row sort, three launches.  mask [E_parent] u8; child arrays sized as for sgs_graph_build(q, N).
+ * Result is identical to sgs_graph_build on the compacted edge list. */
+size_t sgs_graph_filter_workspace_bytes(int64_t E_parent, int64_t N);
+int sgs_graph_filter(const int32_t* pin_ptr, const int32_t* pin_src, const int32_t* pin_eid, const int32_t* pout_ptr,
+                     const int32_t* pout_dst, const int32_t* pout_eid, int64_t E_parent, int64_t N, const uint8_t* mask,
+                     const int64_t* sampled_eid, int64_t q, int32_t* in_ptr, int32_t* in_src, int32_t* in_eid, int32_t* out_ptr,
+                     int32_t* out_dst, int32_t* out_eid, int32_t* loop_eid, void* ws, size_t ws_bytes, sgs_stream_t stream);
+
 /* gcn_norm forward (PyG gcn_norm, add_self_loops=True, flow source_to_target):
  *   loopw_i = w[loop_eid_i] or 1;  deg_i = loopw_i + sum_{e=(j->i), j!=i} w_e;  dis = deg^-1/2 (inf -> 0)
  *   what_in[k]  = dis[src] * w * dis[dst] in dst-CSR order,  what_out[k] the same in src-CSR order

@@ -215,6 +215,36 @@ class Graph:
                                      ws.data_ptr(), ws.numel(), _stream()), "sgs_graph_build")
 
 
+def get_subgraph(parent_edge_index: torch.Tensor, N: int, sample) -> Graph:
+    """CSR of a drawn subgraph (`sample` = SampleResult of a draw over `parent_edge_index`) squeezed out of the parent's cached
+    CSR (sgs_graph_filter): no atomics and no per-row sort, identical arrays to Graph(sample.edge_index).  The result is cached
+    on `sample.edge_index`, so every later get_graph() on the drawn edge list reuses it."""
+    L = _lib.lib()
+    parent = get_graph(parent_edge_index, N)
+    ei = sample.edge_index
+    n = ei.shape[1]
+    g = Graph.__new__(Graph)
+    g.edge_index, g.n_edges, g.N = ei, n, int(N)
+    ne = max(n, 1)
+    sizes = [N + 1, N + 1, ne, ne, ne, ne, max(N, 1)]
+    offs = [0]
+    for z in sizes:
+        offs.append(offs[-1] + ((z + 63) & ~63))
+    buf = torch.empty(offs[-1], dtype=torch.int32, device=ei.device)
+    (g.in_ptr, g.out_ptr, g.in_src, g.in_eid, g.out_dst, g.out_eid, g.loop_eid) = (buf[offs[i]:offs[i] + sizes[i]] for i in range(7))
+    ws = workspace(L.sgs_graph_filter_workspace_bytes(parent.n_edges, N), ei.device)
+    _lib.check(L.sgs_graph_filter(_ptr(parent.in_ptr), _ptr(parent.in_src), _ptr(parent.in_eid), _ptr(parent.out_ptr), _ptr(parent.out_dst),
+                                  _ptr(parent.out_eid), parent.n_edges, N, _ptr(_u8(sample.mask)), _ptr(sample.eid, torch.int64), n,
+                                  _ptr(g.in_ptr), _ptr(g.in_src), _ptr(g.in_eid), _ptr(g.out_ptr), _ptr(g.out_dst), _ptr(g.out_eid),
+                                  _ptr(g.loop_eid), ws.data_ptr(), ws.numel(), _stream()), "sgs_graph_filter")
+    try:
+        ei._sgs_graph = g
+        ei._sgs_graph_version = ei._version
+    except Exception:
+        pass
+    return g
+
+
 def get_graph(edge_index: torch.Tensor, N: int) -> Graph:
     """Graph for `edge_index`, cached ON the tensor object (dies with it; keyed by its version
     counter), so the encoder and the GNN that receive the same tensor share one build."""

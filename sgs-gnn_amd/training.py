@@ -70,6 +70,7 @@ def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise
     if args.conditional or args.sparse_edge_mlp:                      # K0: prior-only draw
         rs = draw_prior(batch.prob, batch.edge_index, q, noise=noise.get("prior"))
         st.rsei = rs.edge_index
+        ops.get_subgraph(batch.edge_index, N, rs)                     # CSR of the random graph, squeezed out of the partition's cached CSR
     st.random_out = None
     forked = side_stream is not None and args.conditional and st.rsei is not None
     if forked:
@@ -93,7 +94,7 @@ def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise
     st.smp = smp = draw_learned(batch.prob, st.edge_probs_full, batch.edge_index, q, args.degree_bias_coef,
                                 noise=noise.get("sample"), want_p=(pipeline == "hybrid"))
     st.sampled_edge_index = smp.edge_index
-    graph_s = ops.get_graph(smp.edge_index, N)
+    graph_s = ops.get_subgraph(batch.edge_index, N, smp)
 
     if pipeline == "hybrid":
         # edge_probs_full[mask]: gradient reaches only the q sampled entries

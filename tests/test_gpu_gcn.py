@@ -184,3 +184,24 @@ def test_gemm_tn_tall_with_column_sums(pkg):
     with pytest.raises(RuntimeError):
         pkg._lib.check(L.sgs_gemm_tn_colsum(A.data_ptr(), B.data_ptr(), 100, M, N, C.data_ptr(), cs.data_ptr(), ws.data_ptr(), ws.numel(),
                                             pkg.ops._stream()), "sgs_gemm_tn_colsum")
+
+
+@pytest.mark.parametrize("N,E,q", [(50, 600, 200), (1013, 120000, 40000), (7, 30, 29), (300, 5000, 1)])
+def test_graph_filter_equals_build_of_the_compacted_edges(pkg, N, E, q):
+    """sgs_graph_filter (child CSR squeezed out of the parent's CSR) == sgs_graph_build on the drawn edge list, incl. self loops
+    and duplicate edges."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(N + q)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[:, :5] = ei[0, :5]                                        # some self loops
+    ei = ei[:, torch.argsort(ei[0] * N + ei[1], stable=True)].contiguous().to(DEV)
+    p = torch.rand(E, generator=g).to(DEV)
+    r = ops.sample_topq(ops.SAMPLE_LEARNED, p, None, 0.0, q, ei, seed=3, stream_id=1)
+    child = ops.get_subgraph(ei, N, r)
+    ref = ops.Graph(r.edge_index.clone(), N)
+    torch.cuda.synchronize()
+    for name in ("in_ptr", "out_ptr", "in_src", "in_eid", "out_dst", "out_eid", "loop_eid"):
+        a, b = getattr(child, name), getattr(ref, name)
+        n = q if name in ("in_src", "in_eid", "out_dst", "out_eid") else a.numel()
+        assert torch.equal(a[:n], b[:n]), name
+    assert ops.get_graph(r.edge_index, N) is child               # cached on the drawn edge list
