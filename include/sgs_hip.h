@@ -317,6 +317,8 @@ int sgs_masked_correct(const float* logits, int64_t N, int64_t C, const int64_t*
  * correct4 = {#correct_a, #train, #correct_b, #train}; correct4 must be ZERO on entry (it is accumulated into). */
 int sgs_masked_correct_pair(const float* logits_a, const float* logits_b, int64_t N, int64_t C, const int64_t* y,
                             const uint8_t* train_mask, int32_t* correct4, sgs_stream_t stream);
+/* Closing launch of a replayed step: loss_sum[0] += loss[0] and epoch[0] += 1 (either pair may be NULL). */
+int sgs_loss_tick(float* loss_sum, const float* loss, uint64_t* epoch, sgs_stream_t stream);
 /* Publish n (<= 63) device words to pinned, device-mapped HOST memory: dst[0..n) = src[0..n), then dst[n] = low 32 bits
  * of *seq_dev (NULL: 1) with release semantics at system scope.  A host thread polling dst[n] for a change reads the
  * payload without a copy-engine round trip or a stream synchronisation (the gate read-back of a replayed step). */

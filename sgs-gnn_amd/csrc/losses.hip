@@ -76,6 +76,14 @@ __global__ void __launch_bounds__(1024) masked_correct_pair(const float* __restr
     }
 }
 
+// End of a replayed step in one launch: running loss += this step's loss, RNG epoch += 1 (the next replay draws fresh noise).
+__global__ void loss_tick(float* __restrict__ sum, const float* __restrict__ loss, uint64_t* __restrict__ epoch) {
+    if (threadIdx.x == 0) {
+        if (sum && loss) sum[0] += loss[0];
+        if (epoch) epoch[0] += 1;
+    }
+}
+
 // Hands a few device words to the HOST without a copy engine round trip: `dst` is pinned, device-mapped host memory; the
 // payload is written first, then the sequence word (the RNG epoch, which changes on every graph replay) with release
 // semantics at system scope, so a host thread that polls the sequence word sees the payload.  Used for the gate.
@@ -303,6 +311,13 @@ int sgs_masked_correct_pair(const float* logits_a, const float* logits_b, int64_
     SGS_REQUIRE(logits_a && logits_b && y && train_mask, SGS_EINVAL, "sgs_masked_correct_pair: null pointer");
     hipLaunchKernelGGL(masked_correct_pair, dim3(static_cast<unsigned>(cdiv(N, 16)), 2), dim3(1024), 0, stream, logits_a, logits_b, N, C, y, train_mask,
                        correct4);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_loss_tick(float* loss_sum, const float* loss, uint64_t* epoch, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(loss_tick, dim3(1), dim3(64), 0, stream, loss_sum, loss, epoch);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

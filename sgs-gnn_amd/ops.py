@@ -535,6 +535,14 @@ def masked_correct_pair(logits_a, logits_b, y, train_mask, out) -> torch.Tensor:
     return out
 
 
+def loss_tick(loss_sum, loss, epoch) -> None:
+    """sgs_loss_tick: loss_sum += loss and epoch += 1 in one launch (the last kernel of a replayed step)."""
+    L = _lib.lib()
+    _need_gpu(loss_sum, loss, epoch)
+    _lib.check(L.sgs_loss_tick(_ptr(loss_sum, torch.float32), _ptr(loss.detach().reshape(1), torch.float32), epoch.data_ptr(), _stream()),
+               "sgs_loss_tick")
+
+
 def publish_to_host(src, n, seq, dst_pinned) -> None:
     """sgs_publish_to_host: src (device int32) -> dst_pinned (pinned host int32, >= n + 1 entries); seq: device int64 word."""
     L = _lib.lib()

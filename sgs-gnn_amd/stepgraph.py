@@ -5,11 +5,12 @@ microseconds each, and the Python + launch time per step exceeds the GPU-busy ti
 The C ABI never allocates or synchronises, so a step's device work is capturable as is.  Per partition
 (keyed on the batch's tensors) the step is recorded once into HIP graphs and replayed afterwards:
 
-    E_b >  q :  G1 = epoch += 1; prior draw -> scores -> learned draw -> CSR build -> learned / random encoders ->
+    E_b >  q :  G1 = prior draw -> scores -> learned draw -> CSR build -> learned / random encoders ->
                      the two correct-counts -> publish them to pinned host memory   (training.sampled_forward)
                 the host polls the gate words (the step's one read-back; eager mode does a 20-byte copy instead)
                 G2L = CE + reg1 + reg2, backward of the learned branch   |   G2R = CE, backward of the random branch
-    E_b <= q :  G  = epoch += 1; encoder on all edges, CE, backward
+    E_b <= q :  G  = encoder on all edges, CE, backward
+    every step's last launch adds its loss to the running sum and bumps the RNG epoch (sgs_loss_tick)
 
 Optimisers: `capturable` ones (sgs_gnn_amd.FusedAdam, or torch's with capturable=True) are recorded at the end of the
 backward graphs -- their state is created before any capture, a state tensor born inside a capture would be reset by
@@ -19,7 +20,7 @@ Data parallel (N > 1, FusedAdam): the backward graphs accumulate straight into G
 and add one "this rank learned" word; the trainer issues ONE all-reduce and replays g3, a single shared graph that divides
 by the world size and steps both optimisers with the all-reduced word read on the device (FusedAdam's per-tensor gate).
 
-Randomness: seeds are launch arguments and therefore frozen at capture; every capture starts by
+Randomness: seeds are launch arguments and therefore frozen at capture; every replayed step ends by
 incrementing the registered RNG epoch word (ops.set_rng_epoch_buffer) which all RNG-consuming kernels fold
 into their seed, so each replay draws fresh Exp(1) noise and dropout masks.  The random stream therefore
 differs from eager mode's (same distributions); parity tests run eager mode.
@@ -111,7 +112,10 @@ class StepGraphs:
         self.use_checkpoint = use_checkpoint
         self.params = [p for p in model.parameters()]
         self.device = self.params[0].device
+        # RNG epoch: 0 during the eager warm-up visits, then the 1-based index of the replayed step (set to 1 by the first
+        # capture, ticked by each replayed step's last launch)
         self.epoch_word = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._epoch_started = False
         # warm-up visits and captures share one side stream: autograd stamps every node (AccumulateGrad included)
         # with the stream it was created on, and a capture must not meet nodes from the legacy default stream
         self.stream = torch.cuda.Stream(device=self.device)
@@ -125,6 +129,7 @@ class StepGraphs:
         # device-mapped host memory (sgs_publish_to_host) and the trainer polls the sequence word
         self.host_gate = torch.zeros(8, dtype=torch.int32).pin_memory()
         self.host_gate_np = self.host_gate.numpy()
+        self.host_gate_np[4] = -1                       # sequence word: differs from any epoch value a replay will publish
         self.table = {}          # batch key -> _Captured | "seen"
         self.cfg = self._config_key()
 
@@ -212,6 +217,9 @@ class StepGraphs:
 
     def _capture_segments(self, batch, key) -> _Captured:
         from .training import _ce, learned_loss, sampled_forward
+        if not self._epoch_started:
+            self.epoch_word.fill_(1)
+            self._epoch_started = True
         a = self.args
         c = _Captured()
         for name in _Captured.__slots__:
@@ -230,7 +238,6 @@ class StepGraphs:
             if self.dp:
                 self._bind_bucket()
             with torch.cuda.graph(c.g1, stream=self.stream, capture_error_mode=self.capture_mode):
-                self.epoch_word.add_(1)
                 if self.dp:
                     self.sync.flat.zero_()                         # gradients of this step + flag word (0: nobody learned here)
                 out = self.model(batch, batch.edge_index)
@@ -238,13 +245,12 @@ class StepGraphs:
                 c.loss.backward(gradient=self.one)
                 if self.optimizers is not None and not self.dp:
                     self.optimizers[1].step()                      # optimizer_gnn (training_hybrid.py:161)
-                self.loss_sum.add_(c.loss.detach())
+                ops.loss_tick(self.loss_sum, c.loss, self.epoch_word)     # + RNG epoch: the next replay draws fresh noise
             c.grads = self._grads()
             c.loss = c.loss.detach()
             self._clear_grads()
             return c
         with torch.cuda.graph(c.g1, stream=self.stream, capture_error_mode=self.capture_mode):
-            self.epoch_word.add_(1)
             st = sampled_forward(self.pipeline, a, self.model, batch, self.q, self.use_checkpoint,
                                  side_stream=self.side if _DEBUG == "fork" else None)   # measured: a forked capture is SLOWER here (below)
             if st.cbuf is not None:
@@ -270,7 +276,7 @@ class StepGraphs:
             elif self.optimizers is not None:
                 self.optimizers[0].step()                          # optimizer_edge_prob, then optimizer_gnn (:136-137)
                 self.optimizers[1].step()
-            self.loss_sum.add_(loss_l.detach())
+            ops.loss_tick(self.loss_sum, loss_l, self.epoch_word)
         c.grads_l = self._grads()
         c.loss_l = loss_l.detach()
         self._clear_grads()
@@ -286,7 +292,7 @@ class StepGraphs:
                 loss_r.backward(gradient=self.one)
                 if self.optimizers is not None and not self.dp:
                     self.optimizers[1].step()                      # optimizer_gnn only (:141)
-                self.loss_sum.add_(loss_r.detach())
+                ops.loss_tick(self.loss_sum, loss_r, self.epoch_word)
             c.grads_r = self._grads()
             c.loss_r = loss_r.detach()
             self._clear_grads()

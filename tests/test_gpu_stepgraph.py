@@ -145,7 +145,7 @@ def test_sampled_replay_matches_eager_recomputation_from_its_own_draws(pipeline)
         # every replay drew a different edge set; resetting the epoch word reproduces a replay exactly
         assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
         e = int(sg.epoch_word.item())
-        sg.epoch_word.fill_(e - 1)
+        sg.epoch_word.fill_(e - 2)                     # each iteration replayed G2L and G2R: two epoch ticks after the last G1
         c.g1.replay()
         torch.cuda.synchronize()
         assert torch.equal(c.keep["eid"], seen[2])
