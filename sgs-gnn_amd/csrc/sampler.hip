@@ -108,18 +108,23 @@ __global__ void __launch_bounds__(kThreads) keys_hist0(const float* __restrict__
     const float Zeps = (MODE == SGS_SAMPLE_LEARNED) ? __fadd_rn(Z, 1e-12f) : Z;
     const float mx = (MODE == SGS_SAMPLE_PRIOR) ? scal[1] : 0.f;
     const bool has_prior = prior != nullptr;
-    const int64_t base = static_cast<int64_t>(blockIdx.x) * kChunk;
+    // grid-stride over the 2048-edge chunks: at full-graph scale (56 k chunks) a workgroup per chunk would flush 56 k
+    // private histograms into the 2048 global bins; a capped grid flushes a few thousand
+    const int64_t nchunk = (E + kChunk - 1) / kChunk;
+    for (int64_t chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
+        const int64_t base = chunk * kChunk;
 #pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
-        if (e < E) {
-            const float s = sample_prob<MODE>(p[e], Zeps, mx, has_prior ? prior[e] : 0.f, has_prior, one_minus_c, c);
-            const float nz = noise ? noise[e] : exp_noise_at(seed, stream_id, static_cast<uint64_t>(edge_offset + e));
-            const float key = __fdiv_rn(s, nz);
-            const uint32_t bits = __float_as_uint(key);
-            keys[e] = bits;
-            if (keys_out) keys_out[e] = key;
-            atomicAdd(&lh[bits >> kShift0], 1u);
+        for (int i = 0; i < kItems; ++i) {
+            const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
+            if (e < E) {
+                const float s = sample_prob<MODE>(p[e], Zeps, mx, has_prior ? prior[e] : 0.f, has_prior, one_minus_c, c);
+                const float nz = noise ? noise[e] : exp_noise_at(seed, stream_id, static_cast<uint64_t>(edge_offset + e));
+                const float key = __fdiv_rn(s, nz);
+                const uint32_t bits = __float_as_uint(key);
+                keys[e] = bits;
+                if (keys_out) keys_out[e] = key;
+                atomicAdd(&lh[bits >> kShift0], 1u);
+            }
         }
     }
     __syncthreads();
@@ -137,13 +142,16 @@ __global__ void __launch_bounds__(kThreads) hist_next(const uint32_t* __restrict
     for (int i = threadIdx.x; i < kBins; i += kThreads) lh[i] = 0;
     __syncthreads();
     const uint32_t want = st->prefix >> prev_shift;
-    const int64_t base = static_cast<int64_t>(blockIdx.x) * kChunk;
+    const int64_t nchunk = (E + kChunk - 1) / kChunk;
+    for (int64_t chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
+        const int64_t base = chunk * kChunk;
 #pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
-        if (e < E) {
-            const uint32_t bits = keys[e];
-            if ((bits >> prev_shift) == want) atomicAdd(&lh[(bits >> shift) & digit_mask], 1u);
+        for (int i = 0; i < kItems; ++i) {
+            const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
+            if (e < E) {
+                const uint32_t bits = keys[e];
+                if ((bits >> prev_shift) == want) atomicAdd(&lh[(bits >> shift) & digit_mask], 1u);
+            }
         }
     }
     __syncthreads();
@@ -306,6 +314,19 @@ __device__ __forceinline__ void compact_body(uint32_t blk_gt, uint32_t blk_eq, c
     bg += ig - gt;   // #gt with lower id (global)
     be += ie - eq;   // #eq with lower id (global)
     uint64_t mbits = 0;
+    // The endpoint columns of this thread's 8 candidates are loaded UNCONDITIONALLY as four 16-byte vectors per row of
+    // edge_index when the tile is whole: at the usual 20 % keep rate a predicated 8-byte gather touches nearly every cache
+    // line anyway, and at full-graph scale (E = 114.6 M) the streaming form is what HBM delivers at speed.
+    const bool whole = e0 + kItems <= E && sei != nullptr && ((reinterpret_cast<uintptr_t>(edge_index) | (static_cast<uint64_t>(E) * 8)) & 15) == 0;
+    int64_t sv[kItems], dv[kItems];
+    if (whole) {
+#pragma unroll
+        for (int j = 0; j < kItems; j += 2) {
+            const longlong2 a = *reinterpret_cast<const longlong2*>(edge_index + e0 + j);
+            const longlong2 b = *reinterpret_cast<const longlong2*>(edge_index + E + e0 + j);
+            sv[j] = a.x; sv[j + 1] = a.y; dv[j] = b.x; dv[j + 1] = b.y;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < kItems; ++j) {
         const int64_t e = e0 + j;
@@ -317,8 +338,8 @@ __device__ __forceinline__ void compact_body(uint32_t blk_gt, uint32_t blk_eq, c
                 const int64_t pos = static_cast<int64_t>(bg) + static_cast<int64_t>(be < k_rem ? be : k_rem);
                 if (sampled_eid) sampled_eid[pos] = eid_offset + e;
                 if (sei) {
-                    sei[pos] = edge_index[e];
-                    sei[q + pos] = edge_index[E + e];
+                    sei[pos] = whole ? sv[j] : edge_index[e];
+                    sei[q + pos] = whole ? dv[j] : edge_index[E + e];
                 }
                 if (sampled_p) sampled_p[pos] = p[e];
             }
@@ -351,7 +372,8 @@ __global__ void __launch_bounds__(kThreads) compact(const uint32_t* __restrict__
 // histograms / counts the previous launch left in memory -- a few KB of L2 reads per workgroup, the same arithmetic in
 // the same order (bit-identical Z, max, threshold), no inter-workgroup synchronisation.  (A "last workgroup done"
 // variant with tickets was measured slower on MI355X: the device-scope fences write back / invalidate the per-XCD L2s.)
-constexpr int kSmallBlocks = 1024;     // small path when E <= 1024 chunks (2 M candidate edges)
+constexpr int kSmallBlocks = 1024;
+constexpr int kHistGrid = 2048;        // workgroups of the histogram passes on the large-E path (grid-stride over chunks)     // small path when E <= 1024 chunks (2 M candidate edges)
 
 struct SelPart { uint32_t prefix, k_rem; };
 
@@ -793,6 +815,7 @@ int sgs_sample_topq(int mode, const float* p, const float* prior, double degree_
     uint32_t* hist3 = cv.take<uint32_t>(3 * kBins);       // fused small-E path: one histogram per digit
     SelPart* sel = cv.take<SelPart>(2);
     const dim3 grid(static_cast<unsigned>(nblk)), blk(kThreads);
+    const dim3 hgrid(static_cast<unsigned>(nblk < kHistGrid ? nblk : kHistGrid));
     // python: (1 - c) and c are doubles, cast to fp32 when they meet the fp32 tensor
     const float one_minus_c = static_cast<float>(1.0 - degree_bias_coef);
     const float c = static_cast<float>(degree_bias_coef);
@@ -846,15 +869,15 @@ int sgs_sample_topq(int mode, const float* p, const float* prior, double degree_
     }
 
     if (mode == SGS_SAMPLE_LEARNED)
-        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_LEARNED>, grid, blk, 0, stream, p, prior, noise, seed, stream_id, epoch_ptr(), int64_t(0), E,
+        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_LEARNED>, hgrid, blk, 0, stream, p, prior, noise, seed, stream_id, epoch_ptr(), int64_t(0), E,
                            one_minus_c, c, scal, keys, keys_out, hist);
     else
-        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_PRIOR>, grid, blk, 0, stream, p, nullptr, noise, seed, stream_id, epoch_ptr(), int64_t(0), E,
+        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_PRIOR>, hgrid, blk, 0, stream, p, nullptr, noise, seed, stream_id, epoch_ptr(), int64_t(0), E,
                            one_minus_c, c, scal, keys, keys_out, hist);
     hipLaunchKernelGGL(select_digit, dim3(1), blk, 0, stream, hist, kShift0, 1, static_cast<uint32_t>(q), st);
-    hipLaunchKernelGGL(hist_next, grid, blk, 0, stream, keys, E, kShift1, kMask1, kShift0, st, hist);
+    hipLaunchKernelGGL(hist_next, hgrid, blk, 0, stream, keys, E, kShift1, kMask1, kShift0, st, hist);
     hipLaunchKernelGGL(select_digit, dim3(1), blk, 0, stream, hist, kShift1, 0, static_cast<uint32_t>(q), st);
-    hipLaunchKernelGGL(hist_next, grid, blk, 0, stream, keys, E, kShift2, kMask2, kShift1, st, hist);
+    hipLaunchKernelGGL(hist_next, hgrid, blk, 0, stream, keys, E, kShift2, kMask2, kShift1, st, hist);
     hipLaunchKernelGGL(select_digit, dim3(1), blk, 0, stream, hist, kShift2, 0, static_cast<uint32_t>(q), st);
     hipLaunchKernelGGL(count_blocks, grid, blk, 0, stream, keys, E, st, cnt);
     hipLaunchKernelGGL(scan_blocks, dim3(1), blk, 0, stream, cnt, nblk);
@@ -910,12 +933,13 @@ int sgs_sampler_shard_keys(int mode, const float* p, const float* prior, double 
     if (E == 0) return SGS_OK;
     SGS_REQUIRE(p && scal && keys && hist, SGS_EINVAL, "sgs_sampler_shard_keys: null pointer");
     const float one_minus_c = static_cast<float>(1.0 - degree_bias_coef), c = static_cast<float>(degree_bias_coef);
-    const dim3 grid(static_cast<unsigned>(cdiv(E, kChunk))), blk(kThreads);
+    const int64_t nb_ = cdiv(E, kChunk);
+    const dim3 hgrid(static_cast<unsigned>(nb_ < kHistGrid ? nb_ : kHistGrid)), blk(kThreads);
     if (mode == SGS_SAMPLE_LEARNED)
-        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_LEARNED>, grid, blk, 0, stream, p, prior, noise, seed, stream_id, epoch_ptr(), edge_offset, E,
+        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_LEARNED>, hgrid, blk, 0, stream, p, prior, noise, seed, stream_id, epoch_ptr(), edge_offset, E,
                            one_minus_c, c, scal, keys, keys_out, hist);
     else
-        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_PRIOR>, grid, blk, 0, stream, p, nullptr, noise, seed, stream_id, epoch_ptr(), edge_offset, E,
+        hipLaunchKernelGGL(keys_hist0<SGS_SAMPLE_PRIOR>, hgrid, blk, 0, stream, p, nullptr, noise, seed, stream_id, epoch_ptr(), edge_offset, E,
                            one_minus_c, c, scal, keys, keys_out, hist);
     SGS_LAUNCH_OK();
     return SGS_OK;
@@ -925,9 +949,10 @@ int sgs_sampler_shard_hist(const uint32_t* keys, int64_t E, int pass, const void
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     SGS_REQUIRE((pass == 1 || pass == 2) && E >= 0 && state && hist, SGS_EINVAL, "sgs_sampler_shard_hist: bad arguments");
     if (E == 0) return SGS_OK;
-    const dim3 grid(static_cast<unsigned>(cdiv(E, kChunk))), blk(kThreads);
-    if (pass == 1) hipLaunchKernelGGL(hist_next, grid, blk, 0, stream, keys, E, kShift1, kMask1, kShift0, static_cast<const SelectState*>(state), hist);
-    else hipLaunchKernelGGL(hist_next, grid, blk, 0, stream, keys, E, kShift2, kMask2, kShift1, static_cast<const SelectState*>(state), hist);
+    const int64_t nb_ = cdiv(E, kChunk);
+    const dim3 hgrid(static_cast<unsigned>(nb_ < kHistGrid ? nb_ : kHistGrid)), blk(kThreads);
+    if (pass == 1) hipLaunchKernelGGL(hist_next, hgrid, blk, 0, stream, keys, E, kShift1, kMask1, kShift0, static_cast<const SelectState*>(state), hist);
+    else hipLaunchKernelGGL(hist_next, hgrid, blk, 0, stream, keys, E, kShift2, kMask2, kShift1, static_cast<const SelectState*>(state), hist);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

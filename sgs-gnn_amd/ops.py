@@ -215,10 +215,11 @@ class Graph:
                                      ws.data_ptr(), ws.numel(), _stream()), "sgs_graph_build")
 
 
-def get_subgraph(parent_edge_index: torch.Tensor, N: int, sample) -> Graph:
+def get_subgraph(parent_edge_index: torch.Tensor, N: int, sample, eid=None) -> Graph:
     """CSR of a drawn subgraph (`sample` = SampleResult of a draw over `parent_edge_index`) squeezed out of the parent's cached
     CSR (sgs_graph_filter): no atomics and no per-row sort, identical arrays to Graph(sample.edge_index).  The result is cached
-    on `sample.edge_index`, so every later get_graph() on the drawn edge list reuses it."""
+    on `sample.edge_index`, so every later get_graph() on the drawn edge list reuses it.  `eid`: the selected edges' positions in
+    `parent_edge_index` when they differ from `sample.eid` (edge-sharded draws report GLOBAL ids: pass the local ones)."""
     L = _lib.lib()
     parent = get_graph(parent_edge_index, N)
     ei = sample.edge_index
@@ -234,7 +235,7 @@ def get_subgraph(parent_edge_index: torch.Tensor, N: int, sample) -> Graph:
     (g.in_ptr, g.out_ptr, g.in_src, g.in_eid, g.out_dst, g.out_eid, g.loop_eid) = (buf[offs[i]:offs[i] + sizes[i]] for i in range(7))
     ws = workspace(L.sgs_graph_filter_workspace_bytes(parent.n_edges, N), ei.device)
     _lib.check(L.sgs_graph_filter(_ptr(parent.in_ptr), _ptr(parent.in_src), _ptr(parent.in_eid), _ptr(parent.out_ptr), _ptr(parent.out_dst),
-                                  _ptr(parent.out_eid), parent.n_edges, N, _ptr(_u8(sample.mask)), _ptr(sample.eid, torch.int64), n,
+                                  _ptr(parent.out_eid), parent.n_edges, N, _ptr(_u8(sample.mask)), _ptr(sample.eid if eid is None else eid, torch.int64), n,
                                   _ptr(g.in_ptr), _ptr(g.in_src), _ptr(g.in_eid), _ptr(g.out_ptr), _ptr(g.out_dst), _ptr(g.out_eid),
                                   _ptr(g.loop_eid), ws.data_ptr(), ws.numel(), _stream()), "sgs_graph_filter")
     try:

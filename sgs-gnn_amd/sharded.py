@@ -200,7 +200,7 @@ def sharded_evaluate_forward(args, model, shard: EdgeShard, q: int, noise_local=
                            shard.bounds, noise_local=noise_local, seed=seed, stream_id=stream_id)
     local_ids = smp.eid - shard.edge_offset
     w = ops.st_weights(p_local, None, args.degree_bias_coef, smp.stats, local_ids)        # sampling.py:137-155 (Z is global)
-    g_s = ops.get_graph(smp.edge_index, N)
+    g_s = ops.get_subgraph(shard.edge_index, N, smp, eid=local_ids)          # squeezed out of the shard's cached CSR
     nms = sharded_norm(g_s, w)
     h1 = sharded_propagate(x @ model.gcn1.lin.weight.t(), nms, model.gcn1.bias, act=ops.ACT_RELU)
     out = sharded_propagate(h1 @ model.gcn2.lin.weight.t(), nms, model.gcn2.bias)
@@ -383,7 +383,7 @@ def train_step_sharded(args, model, shard: EdgeShard, optimizer_gnn, optimizer_e
     seed_n, tick = (0, 0) if noise.get("prior") is not None else _NoiseClock.next()
     rs = dist_sample_topq(ops.SAMPLE_PRIOR, shard.prob, None, 0.0, q, ei, off, bounds, noise_local=noise.get("prior"), seed=seed_n,
                           stream_id=tick)
-    g_r = ops.get_graph(rs.edge_index, N)
+    g_r = ops.get_subgraph(ei, N, rs, eid=rs.eid - off)
     nm_r = sharded_norm_autograd(g_r, None)
     # scorer encoder over the random graph (model.py:106-108)
     h = sharded_gcn_layer(x, sc.gcn1.lin.weight, sc.gcn1.bias, nm_r, act=act, p=p, seed=_DropoutClock.next_seed(), site=SITE_ENC)
@@ -398,7 +398,7 @@ def train_step_sharded(args, model, shard: EdgeShard, optimizer_gnn, optimizer_e
     smp = dist_sample_topq(ops.SAMPLE_LEARNED, p_local, shard.prob, args.degree_bias_coef, q, ei, off, bounds,
                            noise_local=noise.get("sample"), seed=seed_n, stream_id=tick)
     local_ids = smp.eid - off
-    g_s = ops.get_graph(smp.edge_index, N)
+    g_s = ops.get_subgraph(ei, N, smp, eid=local_ids)
     active.set(local_ids, g_s)
     w_local = p_local.index_select(0, local_ids)
     nm_s = sharded_norm_autograd(g_s, w_local)
