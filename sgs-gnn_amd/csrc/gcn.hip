@@ -231,6 +231,26 @@ __global__ void __launch_bounds__(kT) sort_rows(int64_t n_wave_blocks, const int
 // no atomics, no per-row sort.  Three launches instead of the five of sgs_graph_build, and none of them is the row sort
 // (19 us at partition scale):  (1) one wave per parent row counts its selected entries; spare workgroups scatter
 // pos[sampled_eid[j]] = j;  (2) scan_counts;  (3) one wave per parent row compacts its entries with a ballot prefix.
+// Large parents (>= 8 M edges): the byte mask (E bytes) is first packed into a bit mask (E/8 bytes) so that the random
+// `mask[eid]` lookups along the in-rows hit a 14 MB table (L2 / Infinity Cache resident) instead of a 114 MB one.
+__global__ void __launch_bounds__(kT) pack_mask_bits(const uint8_t* __restrict__ mask, int64_t E, uint32_t* __restrict__ bits) {
+    const int64_t w = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;        // one 32-edge word per thread
+    if (w * 32 >= E) return;
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int64_t e = w * 32 + j;
+        if (e < E && mask[e]) v |= 1u << j;
+    }
+    bits[w] = v;
+}
+template <bool BITS>
+__device__ __forceinline__ bool mask_at(const uint8_t* __restrict__ mask, int e) {
+    if (BITS) return (reinterpret_cast<const uint32_t*>(mask)[e >> 5] >> (e & 31)) & 1u;
+    return mask[e] != 0;
+}
+
+template <bool BITS>
 __global__ void __launch_bounds__(kT) filter_count_scatter(const int* __restrict__ in_ptr, const int* __restrict__ in_eid,
                                                           const int* __restrict__ out_ptr, const int* __restrict__ out_eid, int64_t N,
                                                           const uint8_t* __restrict__ mask, const int64_t* __restrict__ sampled_eid,
@@ -249,11 +269,12 @@ __global__ void __launch_bounds__(kT) filter_count_scatter(const int* __restrict
     const int* ptr = out ? out_ptr : in_ptr;
     const int* eid = out ? out_eid : in_eid;
     int c = 0;
-    for (int k = ptr[row] + lane; k < ptr[row + 1]; k += 64) c += mask[eid[k]] ? 1 : 0;
+    for (int k = ptr[row] + lane; k < ptr[row + 1]; k += 64) c += mask_at<BITS>(mask, eid[k]) ? 1 : 0;
     c = wave_sum_int_all(c);
     if (lane == 0) (out ? cnt_out : cnt_in)[row] = c;
 }
 
+template <bool BITS>
 __global__ void __launch_bounds__(kT) filter_fill(const int* __restrict__ pin_ptr, const int* __restrict__ pin_src, const int* __restrict__ pin_eid,
                                                  const int* __restrict__ pout_ptr, const int* __restrict__ pout_dst,
                                                  const int* __restrict__ pout_eid, int64_t N, const uint8_t* __restrict__ mask,
@@ -279,7 +300,7 @@ __global__ void __launch_bounds__(kT) filter_fill(const int* __restrict__ pin_pt
         bool sel = false;
         if (k < e) {
             const int pe = peid[k];
-            sel = mask[pe] != 0;
+            sel = mask_at<BITS>(mask, pe);
             if (sel) { col = pcol[k]; ne = pos[pe]; }
         }
         const unsigned long long bal = __ballot(sel);
@@ -825,7 +846,7 @@ int sgs_graph_build(const int64_t* edge_index, int64_t n_edges, int64_t N, int32
 size_t sgs_graph_filter_workspace_bytes(int64_t E_parent, int64_t N) {
     if (E_parent < 0) E_parent = 0;
     if (N < 0) N = 0;
-    return 4 * carve_bytes(N + 1, 4) + carve_bytes(E_parent + 1, 4) + 256;
+    return 4 * carve_bytes(N + 1, 4) + carve_bytes(E_parent + 1, 4) + carve_bytes(E_parent / 32 + 2, 4) + 256;
 }
 
 int sgs_graph_filter(const int32_t* pin_ptr, const int32_t* pin_src, const int32_t* pin_eid, const int32_t* pout_ptr,
@@ -845,12 +866,24 @@ int sgs_graph_filter(const int32_t* pin_ptr, const int32_t* pin_src, const int32
     int* cur_in = cv.take<int>(N + 1);       // scan_counts also initialises fill cursors; unused here
     int* cur_out = cv.take<int>(N + 1);
     int* pos = cv.take<int>(E_parent + 1);
+    uint32_t* bits = cv.take<uint32_t>(E_parent / 32 + 2);
     const int64_t n_row_blocks = cdiv(2 * N * 64, kT);
-    hipLaunchKernelGGL(filter_count_scatter, dim3(static_cast<unsigned>(n_row_blocks + cdiv(q, kT))), dim3(kT), 0, stream, pin_ptr, pin_eid,
-                       pout_ptr, pout_eid, N, mask, sampled_eid, q, n_row_blocks, cnt_in, cnt_out, pos);
-    hipLaunchKernelGGL(scan_counts, dim3(2), dim3(1024), 0, stream, cnt_in, cnt_out, N, in_ptr, out_ptr, cur_in, cur_out);
-    hipLaunchKernelGGL(filter_fill, dim3(static_cast<unsigned>(n_row_blocks)), dim3(kT), 0, stream, pin_ptr, pin_src, pin_eid, pout_ptr, pout_dst,
-                       pout_eid, N, mask, pos, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, loop_eid);
+    const dim3 g1(static_cast<unsigned>(n_row_blocks + cdiv(q, kT))), g3(static_cast<unsigned>(n_row_blocks)), blk(kT);
+    if (E_parent >= (int64_t(1) << 23)) {
+        hipLaunchKernelGGL(pack_mask_bits, dim3(static_cast<unsigned>(cdiv(cdiv(E_parent, 32), kT))), blk, 0, stream, mask, E_parent, bits);
+        const uint8_t* bm = reinterpret_cast<const uint8_t*>(bits);
+        hipLaunchKernelGGL(filter_count_scatter<true>, g1, blk, 0, stream, pin_ptr, pin_eid, pout_ptr, pout_eid, N, bm, sampled_eid, q, n_row_blocks,
+                           cnt_in, cnt_out, pos);
+        hipLaunchKernelGGL(scan_counts, dim3(2), dim3(1024), 0, stream, cnt_in, cnt_out, N, in_ptr, out_ptr, cur_in, cur_out);
+        hipLaunchKernelGGL(filter_fill<true>, g3, blk, 0, stream, pin_ptr, pin_src, pin_eid, pout_ptr, pout_dst, pout_eid, N, bm, pos, in_ptr, in_src,
+                           in_eid, out_ptr, out_dst, out_eid, loop_eid);
+    } else {
+        hipLaunchKernelGGL(filter_count_scatter<false>, g1, blk, 0, stream, pin_ptr, pin_eid, pout_ptr, pout_eid, N, mask, sampled_eid, q,
+                           n_row_blocks, cnt_in, cnt_out, pos);
+        hipLaunchKernelGGL(scan_counts, dim3(2), dim3(1024), 0, stream, cnt_in, cnt_out, N, in_ptr, out_ptr, cur_in, cur_out);
+        hipLaunchKernelGGL(filter_fill<false>, g3, blk, 0, stream, pin_ptr, pin_src, pin_eid, pout_ptr, pout_dst, pout_eid, N, mask, pos, in_ptr,
+                           in_src, in_eid, out_ptr, out_dst, out_eid, loop_eid);
+    }
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

@@ -118,3 +118,22 @@ def test_reddit_scale_node_count_generic_paths():
     r = ops.sample_topq(ops.SAMPLE_LEARNED, p, None, 0.3, q, ei, seed=3, stream_id=1)
     assert int(r.mask.sum()) == q and r.edge_index.shape == (2, q)
     assert torch.equal(r.edge_index[:, :1000], ei[:, r.mask][:, :1000])
+
+
+def test_graph_filter_bitmask_path_equals_build():
+    """sgs_graph_filter on a parent of >= 2^23 edges (bit-mask lookups) == sgs_graph_build of the drawn edge list."""
+    import sgs_gnn_amd as S
+    ops = S.ops
+    N, E, q = 20000, 9_000_000, 1_700_001
+    g = torch.Generator(device=DEV).manual_seed(3)
+    ei = torch.randint(0, N, (2, E), device=DEV, generator=g)
+    ei = ei[:, torch.argsort(ei[0] * N + ei[1])].contiguous()
+    p = torch.rand(E, device=DEV, generator=g)
+    r = ops.sample_topq(ops.SAMPLE_LEARNED, p, None, 0.0, q, ei, seed=3, stream_id=1)
+    child = ops.get_subgraph(ei, N, r)
+    ref = ops.Graph(r.edge_index.clone(), N)
+    torch.cuda.synchronize()
+    for name in ("in_ptr", "out_ptr", "in_src", "in_eid", "out_dst", "out_eid", "loop_eid"):
+        a, b = getattr(child, name), getattr(ref, name)
+        n = q if name in ("in_src", "in_eid", "out_dst", "out_eid") else a.numel()
+        assert torch.equal(a[:n], b[:n]), name
