@@ -214,7 +214,8 @@ def main():
         big = max(pool, key=lambda b: b.edge_index.shape[1])
         L = S._lib.lib()
         alts = {}
-        names = {0: "lds_tiled", 1: "stream_32_edge_wave_tile", 2: "weight_stationary_persistent", 3: "stream_64_edge_wave_tile"}
+        names = {0: "lds_tiled", 1: "stream_32_edge_wave_tile", 2: "weight_stationary_persistent", 3: "stream_64_edge_wave_tile",
+                 4: "bf16x6_split_on_bf16_mfma"}
         used = a.score_variant if a.score_variant >= 0 else 3           # automatic choice at this E (>= 65 536 edges)
         for v, name in names.items():                                      # in-process A/B of the scorer forward kernels
             if v == used:

@@ -286,7 +286,10 @@ void sgs_edge_score_set_bwd_variant(int variant); /* backward core: -1 / 0 = LDS
 int sgs_edge_score_bwd_tile(void);              /* active rows per hdz_part row (64) */
 void sgs_edge_score_set_variant(int variant);   /* forward kernel: -1 = automatic (default: 3 when E >= 65 536, else 1),
                                                   * 0 = LDS-tiled, 1 = register-streaming (32-edge wave tile), 2 = weight-stationary
-                                                  * persistent, 3 = register-streaming with a 64-edge wave tile; all give the same p */
+                                                  * persistent, 3 = register-streaming with a 64-edge wave tile, 4 = bf16x6: exact
+                                                  * 3-way bf16 splits of both operands, six v_mfma_f32_32x32x16_bf16 per fp32
+                                                  * product (fp32-faithful; H % 128 == 0, else 3); all give the same p to fp32
+                                                  * rounding */
 int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
                        int64_t edge_id_offset, const float* W1, const float* b1, const float* w2, const float* b2,
                        float p_drop, uint64_t seed, uint32_t site, float* p_out, void* ws, size_t ws_bytes,

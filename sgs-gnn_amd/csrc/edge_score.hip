@@ -659,6 +659,221 @@ __global__ void __launch_bounds__(kT, 2) edge_score_stream64_kernel(ScoreArgs a,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Forward variant E ("bf16x6"): the same fp32 contraction on the bf16 matrix pipe.  Every fp32 operand is split EXACTLY into
+// three bf16 pieces by round-to-nearest residuals, v = v1 + v2 + v3 with |v2| <= 2^-8 |v|, |v3| <= 2^-16 |v| (the last
+// residual has at most 8 significant bits left, so it converts exactly); the product w f is then the sum of nine bf16 x bf16
+// products, each exact in the fp32 accumulator, and the six of order <= 2 (w1 f1, w1 f2, w2 f1, w1 f3, w2 f2, w3 f1) are
+// kept: the three dropped ones are <= 2^-23 |w f| together, i.e. below the rounding error of ONE fp32 multiply, so the
+// result is fp32-faithful (tests/test_gpu_edge_score.py measures it against an fp64 evaluation next to the fp32 MFMA kernels).
+// v_mfma_f32_32x32x16_bf16 retires 16x the flops per cycle of v_mfma_f32_32x32x2_f32, so six of them per fp32 product leave
+// 16/6 = 2.7x the fp32 matrix rate.
+//   * W1a is split once per launch into Wp16[kc][tile t][piece][lane][8 bf16]: the A operand (hidden rows) of lane
+//     (l31, kh) for k = 16 kc + 8 kh .. + 7 is one 16-byte word per piece, and a k-chunk of all H hidden units is one
+//     contiguous block (24 KiB at H = 256) that the workgroup copies into LDS linearly (double-buffered, one barrier per
+//     chunk) and every wave reads back lane-linearly (ds_read_b128, conflict-free);
+//   * a wave owns 32 edges and ALL H hidden units (8 accumulator tiles = 128 registers): its B operand is eight consecutive
+//     fp32 of each endpoint's row of the plain node codes (two 16-byte loads per endpoint per chunk, no re-layout), multiplied
+//     and split in registers (52 vector instructions per 48 MFMAs), and the fc2 reduction never leaves the wave.
+// Requires H % 128 == 0.
+constexpr int kBM4 = 128;     // edges per workgroup: 4 waves x 32 edges
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {       // (bf16(a) low, bf16(b) high), round to nearest even
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+// (a, b) -> packed pieces p1, p2, p3 with a = a1 + a2 + a3 (same for b)
+__device__ __forceinline__ void split3(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    p1 = pk_bf16(a, b);
+    const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xFFFF0000u);
+    p2 = pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(p2 << 16), sb = rb - __uint_as_float(p2 & 0xFFFF0000u);
+    p3 = pk_bf16(sa, sb);
+}
+
+__global__ void __launch_bounds__(kT) pack_w1a_bf16x3(const float* __restrict__ W1, int H, uint4* __restrict__ Wp16) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;       // one (kc, t, lane)
+    const int NTl = H / 32;
+    if (i >= static_cast<int64_t>(H / 16) * NTl * 64) return;
+    const int lane = i & 63;
+    const int64_t rest = i >> 6;
+    const int t = static_cast<int>(rest % NTl), kc = static_cast<int>(rest / NTl);
+    const int h = 32 * t + (lane & 31), k0 = 16 * kc + 8 * (lane >> 5);
+    const float* w = W1 + static_cast<int64_t>(h) * 2 * H + k0;
+    uint32_t p[3][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) split3(w[2 * m], w[2 * m + 1], p[0][m], p[1][m], p[2][m]);
+    uint4* o = Wp16 + (static_cast<int64_t>(kc) * NTl + t) * 3 * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c * 64] = make_uint4(p[c][0], p[c][1], p[c][2], p[c][3]);
+}
+
+template <int NT>
+__global__ void __launch_bounds__(kT, 2) edge_score_bf16x6_kernel(ScoreArgs a, const uint4* __restrict__ Wp16) {
+    constexpr int H = 32 * NT;
+    constexpr int NKC = H / 16;
+    constexpr int CH = NT * 3 * 64;          // 16-byte words per k-chunk of W1a (all hidden units, three pieces)
+    constexpr int SPT = CH / kT;             // 16-byte words copied per thread per chunk
+    static_assert(CH % kT == 0 && (SPT == 3 || SPT == 6), "H must be 128 or 256");
+    __shared__ uint4 wl[2][CH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kh = lane >> 5, l31 = lane & 31;
+    const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kBM4;
+    const int64_t r = row0 + 32 * wave + l31;
+    const bool live = r < a.n;
+    int s = 0, d = 0;
+    int64_t eg_id = 0;
+    if (live) {
+        eg_id = a.active ? a.active[r] : r;
+        s = static_cast<int>(a.src[eg_id]);
+        d = static_cast<int>(a.dst[eg_id]);
+    }
+    const float4* xp = reinterpret_cast<const float4*>(a.codes + static_cast<int64_t>(s) * H + 8 * kh);
+    const float4* yp = reinterpret_cast<const float4*>(a.codes + static_cast<int64_t>(d) * H + 8 * kh);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+    struct Feat { float4 xa, xb, ya, yb; };
+    // W chunk staging: global -> registers at the head of a phase, registers -> LDS at its end (lane-linear both ways).
+    // (global_load_lds was tried first: next to the ordinary feature loads hipcc 7.2 drains vmcnt(0) before the first ds_read
+    //  of every phase, which serialises the prefetch.)  Named registers, not an array: an array indexed inside the lambdas
+    //  ended up in scratch.
+    uint4 s0, s1, s2, s3, s4, s5;
+    auto gload = [&](int kc) {
+        const uint4* g = Wp16 + static_cast<int64_t>(kc) * CH + tid;
+        s0 = g[0]; s1 = g[kT]; s2 = g[2 * kT];
+        if constexpr (SPT > 3) { s3 = g[3 * kT]; s4 = g[4 * kT]; s5 = g[5 * kT]; }
+    };
+    auto lstore = [&](uint4* w) {
+        w[tid] = s0; w[kT + tid] = s1; w[2 * kT + tid] = s2;
+        if constexpr (SPT > 3) { w[3 * kT + tid] = s3; w[4 * kT + tid] = s4; w[5 * kT + tid] = s5; }
+    };
+    auto fload = [&](int kc, Feat& f) {
+        f.xa = xp[4 * kc]; f.xb = xp[4 * kc + 1];
+        f.ya = yp[4 * kc]; f.yb = yp[4 * kc + 1];
+    };
+    struct WF { uint4 q1, q2, q3; };
+    Feat f;
+    gload(0);
+    fload(0, f);
+    lstore(wl[0]);
+    __syncthreads();
+#pragma unroll 1
+    for (int kc = 0; kc < NKC; ++kc) {
+        const uint4* wcur = wl[kc & 1];
+        uint4* wnext = wl[(kc + 1) & 1];
+        const int kn = kc + 1 < NKC ? kc + 1 : NKC - 1;      // the last phase reloads its own chunk: no branches around the loads
+        gload(kn);
+        __builtin_amdgcn_sched_barrier(0);           // the next chunk's loads are issued FIRST: left alone they sink to the barrier
+        u32x4 F1, F2, F3;
+        {
+            uint32_t p1, p2, p3;
+            split3(f.xa.x * f.ya.x, f.xa.y * f.ya.y, p1, p2, p3); F1[0] = p1; F2[0] = p2; F3[0] = p3;
+            split3(f.xa.z * f.ya.z, f.xa.w * f.ya.w, p1, p2, p3); F1[1] = p1; F2[1] = p2; F3[1] = p3;
+            split3(f.xb.x * f.yb.x, f.xb.y * f.yb.y, p1, p2, p3); F1[2] = p1; F2[2] = p2; F3[2] = p3;
+            split3(f.xb.z * f.yb.z, f.xb.w * f.yb.w, p1, p2, p3); F1[3] = p1; F2[3] = p2; F3[3] = p3;
+        }
+        const bf16x8 f1 = __builtin_bit_cast(bf16x8, F1), f2 = __builtin_bit_cast(bf16x8, F2), f3 = __builtin_bit_cast(bf16x8, F3);
+        __builtin_amdgcn_sched_barrier(0);
+        fload(kn, f);                                // the fp32 features are dead after the split: the next chunk lands in the same registers
+        // W fragments one tile ahead of the MFMAs that use them (the compiler, left alone, reads each just in time and
+        // exposes the LDS latency eight times per chunk)
+        auto wload = [&](int t, WF& w) {
+            w.q1 = wcur[(t * 3 + 0) * 64 + lane];
+            w.q2 = wcur[(t * 3 + 1) * 64 + lane];
+            w.q3 = wcur[(t * 3 + 2) * 64 + lane];
+        };
+        auto six = [&](int t, const WF& w) {
+            const bf16x8 w1 = __builtin_bit_cast(bf16x8, w.q1), w2 = __builtin_bit_cast(bf16x8, w.q2), w3 = __builtin_bit_cast(bf16x8, w.q3);
+            // smallest terms first
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, f1, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, f2, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, f3, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, f1, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, f2, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, f1, acc[t], 0, 0, 0);
+        };
+        WF wa, wb;
+        wload(0, wa);
+#pragma unroll
+        for (int t = 0; t < NT; t += 2) {
+            wload(t + 1, wb);
+            __builtin_amdgcn_sched_barrier(0);
+            six(t, wa);
+            if (t + 2 < NT) wload(t + 2, wa);
+            __builtin_amdgcn_sched_barrier(0);
+            six(t + 1, wb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(wnext);
+        __syncthreads();
+    }
+
+    // ---- epilogue (as variants B / D): hidden unit 8 i + j + 4 kh for step i = 4 t + g4; the wave holds every hidden unit
+    const int Hrt = a.H;
+    const float* b1p = a.b1 + 4 * kh;
+    const float* w2p = a.w2 + 4 * kh;
+    struct Epi { float4 us, ud, bb, ww; };
+    const uint32_t rkey = dropout_row_key(fold_epoch(a.seed, a.epoch), a.site, static_cast<uint64_t>(a.row_offset + eg_id));
+    const float* Us = a.U + static_cast<int64_t>(s) * H + 4 * kh;
+    const float* Ud = a.U + static_cast<int64_t>(d) * H + 4 * kh;
+    auto eload = [&](int i, Epi& L) {
+        L.us = *reinterpret_cast<const float4*>(Us + 8 * i);
+        L.ud = *reinterpret_cast<const float4*>(Ud + 8 * i);
+        L.bb = *reinterpret_cast<const float4*>(b1p + 8 * i);
+        L.ww = *reinterpret_cast<const float4*>(w2p + 8 * i);
+    };
+    float z = 0.f;
+    auto estep = [&](int i, const Epi& L) {
+        const int t = i >> 2, g4 = i & 3;
+        const int hb = 8 * i + 4 * kh;
+        const float u4[4] = {L.us.x - L.ud.x, L.us.y - L.ud.y, L.us.z - L.ud.z, L.us.w - L.ud.w};
+        const float b4[4] = {L.bb.x, L.bb.y, L.bb.z, L.bb.w};
+        const float w4[4] = {L.ww.x, L.ww.y, L.ww.z, L.ww.w};
+        uint32_t bits[2] = {0u, 0u};
+        if (a.use_drop) {
+            bits[0] = dropout_pair_bits(rkey, static_cast<uint32_t>(hb >> 1));
+            bits[1] = dropout_pair_bits(rkey, static_cast<uint32_t>((hb >> 1) + 1));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = (acc[t][4 * g4 + j] + u4[j]) + b4[j];
+            float m = v > 0.f ? 1.f : 0.f;
+            if (a.use_drop) {
+                const uint32_t draw = (j & 1) ? (bits[j >> 1] >> 16) : (bits[j >> 1] & 0xFFFFu);
+                m = draw >= a.drop_thresh ? m * a.drop_scale : 0.f;
+            }
+            z = fmaf(w4[j], v * m, z);
+        }
+    };
+    Epi L0, L1;
+    eload(0, L0);
+#pragma unroll
+    for (int i = 0; i < 4 * NT; i += 2) {
+        if (8 * i < Hrt) {                           // always true: one basic block per step bounds the live registers
+            eload(i + 1, L1);
+            estep(i, L0);
+        }
+        if (8 * i + 8 < Hrt) {
+            if (i + 2 < 4 * NT) eload(i + 2, L0);
+            estep(i + 1, L1);
+        }
+    }
+    z += __shfl_xor(z, 32, 64);
+    if (live && kh == 0) {
+        const float zz = z + a.b2[0];
+        a.p_out[r] = 1.0f / (1.0f + expf(-zz));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Forward variant C ("weight-stationary"): PMC on variant B showed 118 M L2 requests per launch
 // (~13 TB/s), two thirds of them re-fetching W1a.  Here a PERSISTENT workgroup keeps one hidden-half of
 // the packed W1a (H/2 x H fp32 = 128 KiB at H = 256; the CU has 160 KiB of LDS) resident for its whole
@@ -1009,7 +1224,7 @@ size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H, int64_t E) {
     if (H < 0) H = 0;
     if (E < 0) E = 0;
     return carve_bytes(static_cast<size_t>(H) * H, 4) + carve_bytes(static_cast<size_t>(N) * H, 4) + carve_bytes(2 * static_cast<size_t>(E), 4) +
-           carve_bytes(64, 4) + 256;
+           carve_bytes(64, 4) + carve_bytes(static_cast<size_t>(H) * H, 8) + 256;
 }
 
 // 0 = LDS-tiled kernel, 1 = register-streaming kernel, 2 = weight-stationary persistent kernel (forward, H % 64 == 0).
@@ -1072,6 +1287,19 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
         SGS_LAUNCH_OK();
         return SGS_OK;
     }
+    if (variant == 4 && H % 128 == 0 && N > 0) {
+        cv.take<float>(2 * static_cast<size_t>(E));
+        cv.take<unsigned int>(64);
+        uint4* Wp16 = cv.take<uint4>(static_cast<size_t>(H) * H * 6 / 16);
+        hipLaunchKernelGGL(pack_w1a_bf16x3, dim3(static_cast<unsigned>(cdiv((H / 16) * (H / 32) * 64, kT))), dim3(kT), 0, stream, W1,
+                           static_cast<int>(H), Wp16);
+        const dim3 grid(static_cast<unsigned>(cdiv(E, kBM4))), blk(kT);
+        if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8>), grid, blk, 0, stream, a, Wp16);
+        else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4>), grid, blk, 0, stream, a, Wp16);
+        SGS_LAUNCH_OK();
+        return SGS_OK;
+    }
+    if (variant == 4) variant = 3;
     if (variant == 3 && H % 64 == 0 && N > 0) {
         {
             const int n_w = static_cast<int>(cdiv(H * H, kT));

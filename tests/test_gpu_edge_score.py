@@ -89,10 +89,11 @@ def test_scorer_tail_and_probability_range(ops):
     assert float((pd.cpu() - po).abs().max()) < 2e-6
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
-@pytest.mark.parametrize("N,H,E,p", [(300, 64, 5001, 0.0), (1013, 256, 30011, 0.3), (200, 128, 77, 0.3)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("N,H,E,p", [(300, 64, 5001, 0.0), (1013, 256, 30011, 0.3), (200, 128, 77, 0.3), (500, 128, 9000, 0.0)])
 def test_all_forward_variants_match_oracle(ops, variant, N, H, E, p):
-    """LDS-tiled (0), register-streaming 32-edge (1) / 64-edge (3) wave tiles and weight-stationary persistent (2) forward kernels."""
+    """LDS-tiled (0), register-streaming 32-edge (1) / 64-edge (3) wave tiles, weight-stationary persistent (2) and
+    bf16x6 split (4; falls back to 3 unless H % 128 == 0) forward kernels."""
     import sgs_gnn_amd as S
     L = S._lib.lib()
     codes, ei, W1, b1, W2, b2, g = _case(N, H, E, 31 + H)
@@ -106,6 +107,32 @@ def test_all_forward_variants_match_oracle(ops, variant, N, H, E, p):
     finally:
         L.sgs_edge_score_set_variant(-1)
     assert float((pd.cpu().double() - po).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("H", [128, 256])
+def test_bf16x6_split_is_fp32_faithful(ops, H):
+    """Variant 4 evaluates the fp32 contraction as six bf16 MFMAs over exact 3-way operand splits.  Its error against an fp64
+    evaluation must be of the same size as that of the fp32 MFMA kernel (variant 3) -- i.e. fp32 rounding, not bf16 rounding --
+    on operands with a wide dynamic range (codes up to ~40, logits of a few units)."""
+    import sgs_gnn_amd as S
+    L = S._lib.lib()
+    N, E = 700, 50000
+    codes, ei, W1, b1, W2, b2, g = _case(N, H, E, 77 + H)
+    codes = codes * torch.exp(torch.randn(N, 1, generator=g))         # per-node scale: products span several binades
+    W2 = W2 * 4
+    po = O.edge_score(codes[ei[0]].double(), codes[ei[1]].double(), W1.double(), b1.double(), W2.double(), b2.double()).squeeze(1)
+    assert float(po.std()) > 0.05                                      # the case is not saturated
+    err = {}
+    try:
+        for v in (3, 4):
+            L.sgs_edge_score_set_variant(v)
+            pd = ops.edge_score(codes.to(DEV), W1.to(DEV), b1.to(DEV), W2.to(DEV), b2.to(DEV), ei.to(DEV))
+            torch.cuda.synchronize()
+            err[v] = float((pd.cpu().double() - po).abs().max())
+    finally:
+        L.sgs_edge_score_set_variant(-1)
+    print("max |p - p_fp64|:", err)
+    assert err[4] <= 2 * err[3] + 6e-8
 
 
 @pytest.mark.parametrize("H,p", [(256, 0.3), (128, 0.0)])
