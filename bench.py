@@ -33,6 +33,11 @@ import torch.distributed as dist  # noqa: E402
 Q = 100_000
 N_NODES, NFEAT, NCLS, HID = 1013, 602, 41, 256
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (= vector peak)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak
+# forward variant 4 evaluates every fp32 product as SIX bf16 MFMA products over exact 3-way operand splits (fp32-faithful,
+# csrc/edge_score.hip): its matrix pipe is the bf16 one and it executes 6x the algorithmic flops, so the kernel's roofline
+# is the bf16 peak / 6 in algorithmic fp32 flops.
+BF16X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 
 
 def make_args(device):
@@ -216,7 +221,7 @@ def main():
         alts = {}
         names = {0: "lds_tiled", 1: "stream_32_edge_wave_tile", 2: "weight_stationary_persistent", 3: "stream_64_edge_wave_tile",
                  4: "bf16x6_split_on_bf16_mfma"}
-        used = a.score_variant if a.score_variant >= 0 else 3           # automatic choice at this E (>= 65 536 edges)
+        used = a.score_variant if a.score_variant >= 0 else 4           # automatic choice at this E (>= 65 536 edges) and H = 256
         for v, name in names.items():                                      # in-process A/B of the scorer forward kernels
             if v == used:
                 continue
@@ -226,6 +231,13 @@ def main():
         L.sgs_edge_score_set_variant(a.score_variant)
         roof = kernel_roofline(S, model, big, reps=20)       # the variant used by the timed steps above
         roof["kernel"] = f"sgs_edge_score_fwd, forward variant {used} ({names[used]})"
+        if used == 4:
+            roof["peak"] = round(BF16X6_PEAK_TFLOPS, 1)
+            roof["frac"] = round(roof["achieved"] / BF16X6_PEAK_TFLOPS, 4)
+            roof["peak_note"] = ("algorithmic fp32 flops; the kernel runs 6 bf16 MFMA products per fp32 product (exact 3-way splits, "
+                                 "fp32-faithful), so peak = dense bf16 MFMA peak 2500 / 6")
+            roof["bf16_mfma_tflops_executed"] = round(6 * roof["achieved"], 1)
+            roof["vs_fp32_mfma_peak"] = round(roof["achieved"] / F32_MFMA_PEAK_TFLOPS, 4)
         roof["alt_variants"] = alts
         rec = {
             "metric": "sampled edges/sec + training steps/sec, Reddit hybrid 20% sparsity",

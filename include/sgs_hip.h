@@ -284,7 +284,7 @@ int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, void* ws, size_
 size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H, int64_t E);   /* E = 0 for the backward core */
 void sgs_edge_score_set_bwd_variant(int variant); /* backward core: -1 / 0 = LDS-tiled (default), 3 = 64-edge streaming loop (A/B: measured slower) */
 int sgs_edge_score_bwd_tile(void);              /* active rows per hdz_part row (64) */
-void sgs_edge_score_set_variant(int variant);   /* forward kernel: -1 = automatic (default: 3 when E >= 65 536, else 1),
+void sgs_edge_score_set_variant(int variant);   /* forward kernel: -1 = automatic (default: when E >= 65 536, 4 if H % 128 == 0 else 3; below that 1),
                                                   * 0 = LDS-tiled, 1 = register-streaming (32-edge wave tile), 2 = weight-stationary
                                                   * persistent, 3 = register-streaming with a 64-edge wave tile, 4 = bf16x6: exact
                                                   * 3-way bf16 splits of both operands, six v_mfma_f32_32x32x16_bf16 per fp32

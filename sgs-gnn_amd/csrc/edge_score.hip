@@ -1231,7 +1231,7 @@ size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H, int64_t E) {
 // A/B switch for benchmarks.  Measured (MI355X, E = 351 194, H = 256, same process): 0 -> 95, 1 -> 100.7, 2 -> 99.5 TFLOP/s;
 // whole-step throughput is equal within noise, so the fastest kernel is the default.
 static int g_bwd_variant = -1;     // -1 / 0: LDS-tiled backward core (default), 3: 64-edge streaming core (A/B only: slower)
-static int g_score_variant = -1;   // -1: automatic (3 when the launch fills the chip with 128-edge workgroups, else 1)
+static int g_score_variant = -1;   // -1: automatic (when the launch fills the chip with 128-edge workgroups: 4 if H % 128 == 0, else 3; otherwise 1)
 void sgs_edge_score_set_variant(int v) { g_score_variant = v; }
 void sgs_edge_score_set_bwd_variant(int v) { g_bwd_variant = v; }
 int sgs_edge_score_bwd_tile(void) { return kBM; }
@@ -1254,7 +1254,7 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
     a.drop_scale = 1.0f / (1.0f - p_drop); a.drop_thresh = dropout_thresh(p_drop); a.seed = seed; a.epoch = epoch_ptr(); a.site = site;
     a.use_drop = p_drop > 0.f; a.p_out = p_out;
     int variant = g_score_variant;
-    if (variant < 0) variant = (cdiv(E, kBM2) >= 512) ? 3 : 1;          // 512 = 2 resident workgroups x 256 CUs
+    if (variant < 0) variant = (cdiv(E, kBM2) >= 512) ? (H % 128 == 0 ? 4 : 3) : 1;          // 512 = 2 resident workgroups x 256 CUs
     if (variant == 2 && H % 64 == 0 && N > 0) {
         float* zpart = cv.take<float>(2 * static_cast<size_t>(E));
         unsigned int* ctr = cv.take<unsigned int>(64);
