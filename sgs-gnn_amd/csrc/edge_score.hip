@@ -675,7 +675,6 @@ __global__ void __launch_bounds__(kT, 2) edge_score_stream64_kernel(ScoreArgs a,
 //     fp32 of each endpoint's row of the plain node codes (two 16-byte loads per endpoint per chunk, no re-layout), multiplied
 //     and split in registers (52 vector instructions per 48 MFMAs), and the fc2 reduction never leaves the wave.
 // Requires H % 128 == 0.
-constexpr int kBM4 = 128;     // edges per workgroup: 4 waves x 32 edges
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 
@@ -711,17 +710,30 @@ __global__ void __launch_bounds__(kT) pack_w1a_bf16x3(const float* __restrict__ 
     for (int c = 0; c < 3; ++c) o[c * 64] = make_uint4(p[c][0], p[c][1], p[c][2], p[c][3]);
 }
 
-template <int NT>
-__global__ void __launch_bounds__(kT, 2) edge_score_bf16x6_kernel(ScoreArgs a, const uint4* __restrict__ Wp16) {
+// Measured (MI355X, E = 351 194, H = 256; launch = pack + kernel): 0.25-0.29 ms by device against 0.42-0.47 ms for variant D
+// in the same process, i.e. 1.1 PFLOP/s of bf16 MFMA work executed.  Timing probes with one ingredient removed each (WRONG
+// results, timing only; they are not kept in the source) moved the launch by: same-row U gathers -4 %, no feature loads
+// -4 %, no W staging -7 %, no barriers +-0, no operand-split arithmetic -1..-4 %, consecutive MFMAs on different accumulators
+// +-0, every tile reading ONE tile's fragments +10 % (slower), second-slot workgroups started half a lifetime late +-0,
+// 8-wave workgroups (half the W traffic) +2 %, two chunks per phase (twice the prefetch distance, 96 KiB of LDS) +5 %,
+// and no epilogue at all -19 %.  No stall source explains the distance to the MFMA bound (0.11 ms at 2.4 GHz): the kernel
+// runs at an effective 2.05 GHz under the counters and the guide's own bf16 loops on random data hold 1.5-1.7 GHz, so it
+// is priced against the clock the chip gives a dense bf16 MFMA stream rather than against stalls.  Counters:
+// SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles x the 8.43 M MFMAs issued, 42 % of the SIMD cycles; no LDS bank conflicts.
+template <int NT, int NW>
+__global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(ScoreArgs a, const uint4* __restrict__ Wp16) {
     constexpr int H = 32 * NT;
-    constexpr int NKC = H / 16;
+    constexpr int NPH = H / 16;              // phases: one 16-deep k-chunk each, one barrier per phase
     constexpr int CH = NT * 3 * 64;          // 16-byte words per k-chunk of W1a (all hidden units, three pieces)
-    constexpr int SPT = CH / kT;             // 16-byte words copied per thread per chunk
-    static_assert(CH % kT == 0 && (SPT == 3 || SPT == 6), "H must be 128 or 256");
+    constexpr int TH = 64 * NW;              // NW waves x 32 edges per workgroup, all reading the same staged chunks of W1a
+    constexpr int SPT = CH / TH;             // 16-byte words copied per thread per phase
+    static_assert(CH % TH == 0 && (SPT == 3 || SPT == 6), "unsupported shape");
     __shared__ uint4 wl[2][CH];
+    __shared__ __attribute__((aligned(16))) float bw[2][H];          // b1, w2 for the epilogue
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = lane >> 5, l31 = lane & 31;
-    const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kBM4;
+    for (int i = tid; i < H; i += TH) { bw[0][i] = a.b1[i]; bw[1][i] = a.w2[i]; }    // (visible after the first barrier below)
+    const int64_t row0 = static_cast<int64_t>(blockIdx.x) * (32 * NW);
     const int64_t r = row0 + 32 * wave + l31;
     const bool live = r < a.n;
     int s = 0, d = 0;
@@ -741,37 +753,32 @@ __global__ void __launch_bounds__(kT, 2) edge_score_bf16x6_kernel(ScoreArgs a, c
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
 
     struct Feat { float4 xa, xb, ya, yb; };
-    // W chunk staging: global -> registers at the head of a phase, registers -> LDS at its end (lane-linear both ways).
+    // W staging: global -> registers at the head of a phase, registers -> LDS at its end (lane-linear both ways).
     // (global_load_lds was tried first: next to the ordinary feature loads hipcc 7.2 drains vmcnt(0) before the first ds_read
     //  of every phase, which serialises the prefetch.)  Named registers, not an array: an array indexed inside the lambdas
     //  ended up in scratch.
     uint4 s0, s1, s2, s3, s4, s5;
-    auto gload = [&](int kc) {
-        const uint4* g = Wp16 + static_cast<int64_t>(kc) * CH + tid;
-        s0 = g[0]; s1 = g[kT]; s2 = g[2 * kT];
-        if constexpr (SPT > 3) { s3 = g[3 * kT]; s4 = g[4 * kT]; s5 = g[5 * kT]; }
+    auto gload = [&](int ph) {
+        const uint4* g = Wp16 + static_cast<int64_t>(ph) * CH + tid;
+        s0 = g[0]; s1 = g[TH]; s2 = g[2 * TH];
+        if constexpr (SPT > 3) { s3 = g[3 * TH]; s4 = g[4 * TH]; s5 = g[5 * TH]; }
     };
     auto lstore = [&](uint4* w) {
-        w[tid] = s0; w[kT + tid] = s1; w[2 * kT + tid] = s2;
-        if constexpr (SPT > 3) { w[3 * kT + tid] = s3; w[4 * kT + tid] = s4; w[5 * kT + tid] = s5; }
+        w[tid] = s0; w[TH + tid] = s1; w[2 * TH + tid] = s2;
+        if constexpr (SPT > 3) { w[3 * TH + tid] = s3; w[4 * TH + tid] = s4; w[5 * TH + tid] = s5; }
     };
     auto fload = [&](int kc, Feat& f) {
         f.xa = xp[4 * kc]; f.xb = xp[4 * kc + 1];
         f.ya = yp[4 * kc]; f.yb = yp[4 * kc + 1];
     };
     struct WF { uint4 q1, q2, q3; };
-    Feat f;
+    Feat fa;
     gload(0);
-    fload(0, f);
+    fload(0, fa);
     lstore(wl[0]);
     __syncthreads();
-#pragma unroll 1
-    for (int kc = 0; kc < NKC; ++kc) {
-        const uint4* wcur = wl[kc & 1];
-        uint4* wnext = wl[(kc + 1) & 1];
-        const int kn = kc + 1 < NKC ? kc + 1 : NKC - 1;      // the last phase reloads its own chunk: no branches around the loads
-        gload(kn);
-        __builtin_amdgcn_sched_barrier(0);           // the next chunk's loads are issued FIRST: left alone they sink to the barrier
+    // one k-chunk: split the (dead afterwards) fp32 features, refill them with chunk `kn_` of the next phase, 6 NT MFMAs
+    auto chunk = [&](const uint4* wcur, Feat& f, int kn_) {
         u32x4 F1, F2, F3;
         {
             uint32_t p1, p2, p3;
@@ -782,7 +789,7 @@ __global__ void __launch_bounds__(kT, 2) edge_score_bf16x6_kernel(ScoreArgs a, c
         }
         const bf16x8 f1 = __builtin_bit_cast(bf16x8, F1), f2 = __builtin_bit_cast(bf16x8, F2), f3 = __builtin_bit_cast(bf16x8, F3);
         __builtin_amdgcn_sched_barrier(0);
-        fload(kn, f);                                // the fp32 features are dead after the split: the next chunk lands in the same registers
+        fload(kn_, f);
         // W fragments one tile ahead of the MFMAs that use them (the compiler, left alone, reads each just in time and
         // exposes the LDS latency eight times per chunk)
         auto wload = [&](int t, WF& w) {
@@ -812,58 +819,65 @@ __global__ void __launch_bounds__(kT, 2) edge_score_bf16x6_kernel(ScoreArgs a, c
             six(t + 1, wb);
         }
         __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll 1
+    for (int ph = 0; ph < NPH; ++ph) {
+        const uint4* wcur = wl[ph & 1];
+        uint4* wnext = wl[(ph + 1) & 1];
+        const int pn = ph + 1 < NPH ? ph + 1 : NPH - 1;      // the last phase reloads its own chunks: no branches around the loads
+        gload(pn);
+        __builtin_amdgcn_sched_barrier(0);           // the next phase's loads are issued FIRST: left alone they sink to the barrier
+        chunk(wcur, fa, pn);
         lstore(wnext);
         __syncthreads();
     }
 
-    // ---- epilogue (as variants B / D): hidden unit 8 i + j + 4 kh for step i = 4 t + g4; the wave holds every hidden unit
+    // ---- epilogue (as variants B / D): hidden unit 8 i + j + 4 kh for step i = 4 t + g4; the wave holds every hidden unit.
+    // Counters showed the waves of this kernel waiting on memory for 60 % of their life, and most of that here: with one step
+    // of look-ahead each of the 32 steps exposed a gather latency.  The main loop's operand registers are dead now, so the
+    // endpoint rows of U are gathered kPF steps ahead, and b1 / w2 (the same for every edge) come from LDS.
+    constexpr int kPF = 8;
     const int Hrt = a.H;
-    const float* b1p = a.b1 + 4 * kh;
-    const float* w2p = a.w2 + 4 * kh;
-    struct Epi { float4 us, ud, bb, ww; };
     const uint32_t rkey = dropout_row_key(fold_epoch(a.seed, a.epoch), a.site, static_cast<uint64_t>(a.row_offset + eg_id));
     const float* Us = a.U + static_cast<int64_t>(s) * H + 4 * kh;
     const float* Ud = a.U + static_cast<int64_t>(d) * H + 4 * kh;
-    auto eload = [&](int i, Epi& L) {
-        L.us = *reinterpret_cast<const float4*>(Us + 8 * i);
-        L.ud = *reinterpret_cast<const float4*>(Ud + 8 * i);
-        L.bb = *reinterpret_cast<const float4*>(b1p + 8 * i);
-        L.ww = *reinterpret_cast<const float4*>(w2p + 8 * i);
-    };
+    float4 us[kPF], ud[kPF];
+#pragma unroll
+    for (int i = 0; i < kPF; ++i) {
+        us[i] = *reinterpret_cast<const float4*>(Us + 8 * i);
+        ud[i] = *reinterpret_cast<const float4*>(Ud + 8 * i);
+    }
     float z = 0.f;
-    auto estep = [&](int i, const Epi& L) {
-        const int t = i >> 2, g4 = i & 3;
-        const int hb = 8 * i + 4 * kh;
-        const float u4[4] = {L.us.x - L.ud.x, L.us.y - L.ud.y, L.us.z - L.ud.z, L.us.w - L.ud.w};
-        const float b4[4] = {L.bb.x, L.bb.y, L.bb.z, L.bb.w};
-        const float w4[4] = {L.ww.x, L.ww.y, L.ww.z, L.ww.w};
-        uint32_t bits[2] = {0u, 0u};
-        if (a.use_drop) {
-            bits[0] = dropout_pair_bits(rkey, static_cast<uint32_t>(hb >> 1));
-            bits[1] = dropout_pair_bits(rkey, static_cast<uint32_t>((hb >> 1) + 1));
-        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float v = (acc[t][4 * g4 + j] + u4[j]) + b4[j];
-            float m = v > 0.f ? 1.f : 0.f;
-            if (a.use_drop) {
-                const uint32_t draw = (j & 1) ? (bits[j >> 1] >> 16) : (bits[j >> 1] & 0xFFFFu);
-                m = draw >= a.drop_thresh ? m * a.drop_scale : 0.f;
+    for (int i = 0; i < 4 * NT; ++i) {
+        if (8 * i < Hrt) {                           // always true: one basic block per step keeps the look-ahead at kPF steps
+            const int t = i >> 2, g4 = i & 3;
+            const int hb = 8 * i + 4 * kh;
+            const float4 bb = *reinterpret_cast<const float4*>(&bw[0][hb]);
+            const float4 ww = *reinterpret_cast<const float4*>(&bw[1][hb]);
+            const float4 su = us[i % kPF], du = ud[i % kPF];
+            const float u4[4] = {su.x - du.x, su.y - du.y, su.z - du.z, su.w - du.w};
+            const float b4[4] = {bb.x, bb.y, bb.z, bb.w};
+            const float w4[4] = {ww.x, ww.y, ww.z, ww.w};
+            if (i + kPF < 4 * NT) {
+                us[i % kPF] = *reinterpret_cast<const float4*>(Us + 8 * (i + kPF));
+                ud[i % kPF] = *reinterpret_cast<const float4*>(Ud + 8 * (i + kPF));
             }
-            z = fmaf(w4[j], v * m, z);
-        }
-    };
-    Epi L0, L1;
-    eload(0, L0);
+            uint32_t bits[2] = {0u, 0u};
+            if (a.use_drop) {
+                bits[0] = dropout_pair_bits(rkey, static_cast<uint32_t>(hb >> 1));
+                bits[1] = dropout_pair_bits(rkey, static_cast<uint32_t>((hb >> 1) + 1));
+            }
 #pragma unroll
-    for (int i = 0; i < 4 * NT; i += 2) {
-        if (8 * i < Hrt) {                           // always true: one basic block per step bounds the live registers
-            eload(i + 1, L1);
-            estep(i, L0);
-        }
-        if (8 * i + 8 < Hrt) {
-            if (i + 2 < 4 * NT) eload(i + 2, L0);
-            estep(i + 1, L1);
+            for (int j = 0; j < 4; ++j) {
+                const float v = (acc[t][4 * g4 + j] + u4[j]) + b4[j];
+                float m = v > 0.f ? 1.f : 0.f;
+                if (a.use_drop) {
+                    const uint32_t draw = (j & 1) ? (bits[j >> 1] >> 16) : (bits[j >> 1] & 0xFFFFu);
+                    m = draw >= a.drop_thresh ? m * a.drop_scale : 0.f;
+                }
+                z = fmaf(w4[j], v * m, z);
+            }
         }
     }
     z += __shfl_xor(z, 32, 64);
@@ -1293,9 +1307,9 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
         uint4* Wp16 = cv.take<uint4>(static_cast<size_t>(H) * H * 6 / 16);
         hipLaunchKernelGGL(pack_w1a_bf16x3, dim3(static_cast<unsigned>(cdiv((H / 16) * (H / 32) * 64, kT))), dim3(kT), 0, stream, W1,
                            static_cast<int>(H), Wp16);
-        const dim3 grid(static_cast<unsigned>(cdiv(E, kBM4))), blk(kT);
-        if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8>), grid, blk, 0, stream, a, Wp16);
-        else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4>), grid, blk, 0, stream, a, Wp16);
+        const dim3 grid(static_cast<unsigned>(cdiv(E, 128))), blk(256);       // 4 waves x 32 edges; two workgroups per CU
+        if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4>), grid, blk, 0, stream, a, Wp16);
+        else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4>), grid, blk, 0, stream, a, Wp16);
         SGS_LAUNCH_OK();
         return SGS_OK;
     }

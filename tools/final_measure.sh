@@ -16,18 +16,18 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch --
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/tools/prof_scorer.py 351194 6 > $O/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $O/seg -- python3 $R/tools/g1_trace.py > $O/seg.log 2>&1
 cd $R
-python tools/pmc_summary.py $O/pmc_sq $O/pmc_fetch $O/pmc_write edge_score_stream64 $O/scorer_pmc.json > /dev/null
+python tools/pmc_summary.py $O/pmc_sq $O/pmc_fetch $O/pmc_write edge_score_bf16x6 $O/scorer_pmc.json > /dev/null
 python tools/g1_trace_analyze.py $O/seg > $O/graph_segments_timeline.txt
 cp $O/stats/*/*kernel_stats.csv $O/bench_kernel_stats.csv
 python - <<PY
 import csv, glob, json
-rows = [r for r in csv.DictReader(open(glob.glob("$O/stats/*/*kernel_trace.csv")[0])) if "edge_score_stream64_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(glob.glob("$O/stats/*/*kernel_trace.csv")[0])) if "edge_score_bf16x6_kernel" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 last = rows[-20:]                      # bench.py's roofline loop: 20 timed launches on the largest partition, issued last
 avg = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last) / len(last) / 1e3
 line = json.loads([l for l in open("$O/stats.log") if l.startswith("{")][-1])
-json.dump({"rocprofv3_kernel_trace_avg_us_last20_stream64": round(avg, 1), "bench_hip_events_ms_per_launch_same_run": line["roofline"]["ms_per_launch"],
-           "note": "events time sgs_edge_score_fwd = operand-pack launch (~5 us) + this kernel"}, open("$O/scorer_agreement.json", "w"), indent=1)
+json.dump({"rocprofv3_kernel_trace_avg_us_last20_bf16x6": round(avg, 1), "bench_hip_events_ms_per_launch_same_run": line["roofline"]["ms_per_launch"],
+           "note": "events time sgs_edge_score_fwd = W1a split/pack launch (~5 us) + this kernel"}, open("$O/scorer_agreement.json", "w"), indent=1)
 PY
 # keep only the small files (the merge-back limit is 64 MiB)
 for d in pmc_sq pmc_fetch pmc_write; do mkdir -p $O/keep_$d; python - <<PY
