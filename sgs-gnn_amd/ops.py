@@ -46,9 +46,31 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_ws_slot = 0
+
+
+class workspace_slot:
+    """Kernels launched inside this context take their scratch from arena `slot` instead of arena 0.  An arena is reused in
+    stream order, so work that may run CONCURRENTLY with the main stream's (stepgraph.py replays the parameter-independent
+    prefix of the next partition on a second stream) must be recorded with its own."""
+
+    def __init__(self, slot: int):
+        self.slot, self.prev = int(slot), 0
+
+    def __enter__(self):
+        global _ws_slot
+        self.prev, _ws_slot = _ws_slot, self.slot
+        return self
+
+    def __exit__(self, *exc):
+        global _ws_slot
+        _ws_slot = self.prev
+        return False
+
+
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only per-device scratch arena (stream-ordered reuse on the current stream)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """Grow-only per-device scratch arena (stream-ordered reuse on the current stream; see workspace_slot)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _ws_slot)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         if ws is not None and _pin_workspaces:

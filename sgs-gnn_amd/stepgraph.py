@@ -12,6 +12,14 @@ The C ABI never allocates or synchronises, so a step's device work is capturable
     E_b <= q :  G  = encoder on all edges, CE, backward
     every step's last launch adds its loss to the running sum and bumps the RNG epoch (sgs_loss_tick)
 
+Prefix prefetch: the head of G1 -- prior draw, CSR of the random graph, its unit normalisation: 12 dependent launches,
+~90 us at 350 k edges -- depends on the partition and the noise alone, not on the parameters.  It is captured as its own
+graph G0 (scratch from its own arena, RNG epoch from its own device word) and, when the trainer names the next batch
+(`forward(batch, next_batch)`), replayed for the NEXT partition on a second stream while the current partition's G1 / gate
+read-back / backward are in flight; G1 of that partition then only waits for an event.  The epoch G0 folds into its noise is
+written by the host (a replayed step ticks the epoch exactly once, so the host knows the next value), which keeps the
+noise stream identical to the unsplit capture.  `SGS_SG_PREFETCH=0` keeps G0 in line on the main stream.
+
 Optimisers: `capturable` ones (sgs_gnn_amd.FusedAdam, or torch's with capturable=True) are recorded at the end of the
 backward graphs -- their state is created before any capture, a state tensor born inside a capture would be reset by
 every replay; others are stepped eagerly after the replay, with `.grad` of every parameter pointed at that graph's static
@@ -39,11 +47,12 @@ import torch
 from . import ops
 
 _DEBUG = os.environ.get("SGS_SG_DEBUG", "")     # "fork": capture the random encoder on a second stream (measured slower)
+_PREFETCH = os.environ.get("SGS_SG_PREFETCH", "1") != "0"
 
 
 class _Captured:
-    __slots__ = ("key", "sampled", "g1", "g2l", "g2r", "cbuf", "loss", "loss_l", "loss_r", "grads", "grads_l", "grads_r",
-                 "keep")
+    __slots__ = ("key", "sampled", "g0", "g1", "g2l", "g2r", "cbuf", "loss", "loss_l", "loss_r", "grads", "grads_l", "grads_r",
+                 "keep", "pre_event", "pre_epoch")
 
 
 def _capturable(opt) -> bool:
@@ -123,6 +132,13 @@ class StepGraphs:
         # with it), but on ROCm 7.2 a two-branch graph costs 133 us of host time per launch instead of 24 us and the GPU time of the
         # segment does not drop (810 vs 790 us): the step got 5 % slower, so the capture stays single-stream.
         self.side = torch.cuda.Stream(device=self.device)
+        # prefix prefetch (module docstring): stream G0 replays run on when they are issued ahead, the epoch word G0's kernels
+        # read, the host's mirror of `epoch_word` (value at the start of the next replayed step), and two events
+        self.pre_stream = torch.cuda.Stream(device=self.device)
+        self.epoch_pre = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.host_epoch = 0
+        self.ev_main = torch.cuda.Event()
+        self.last_pre = None                            # event of the most recent G0 issued on pre_stream
         self.one = torch.ones((), dtype=torch.float32, device=self.device)      # root gradient: saves autograd's ones_like fill per backward
         self.loss_sum = torch.zeros((), dtype=torch.float32, device=self.device)  # replayed steps add their loss here (read once per epoch)
         # gate read-back of a replayed step without a copy-engine round trip: G1 ends by publishing the counts to pinned,
@@ -216,9 +232,10 @@ class StepGraphs:
                 gc.enable()
 
     def _capture_segments(self, batch, key) -> _Captured:
-        from .training import _ce, learned_loss, sampled_forward
+        from .training import _ce, learned_loss, sampled_forward, sampled_prefix
         if not self._epoch_started:
             self.epoch_word.fill_(1)
+            self.host_epoch = 1
             self._epoch_started = True
         a = self.args
         c = _Captured()
@@ -250,9 +267,22 @@ class StepGraphs:
             c.loss = c.loss.detach()
             self._clear_grads()
             return c
-        with torch.cuda.graph(c.g1, stream=self.stream, capture_error_mode=self.capture_mode):
+        pre, pool = None, None
+        if (a.conditional or a.sparse_edge_mlp) and _DEBUG != "fork":
+            # G0: the parameter-independent head, with its own scratch arena and epoch word so that it may run beside the main stream
+            c.g0 = torch.cuda.CUDAGraph()
+            c.pre_event = torch.cuda.Event()
+            ops.set_rng_epoch_buffer(self.epoch_pre)
+            try:
+                with ops.workspace_slot(1), torch.cuda.graph(c.g0, stream=self.stream, capture_error_mode=self.capture_mode):
+                    pre = sampled_prefix(a, batch, self.q)
+            finally:
+                ops.set_rng_epoch_buffer(self.epoch_word)
+            pool = c.g0.pool()
+        with torch.cuda.graph(c.g1, stream=self.stream, pool=pool, capture_error_mode=self.capture_mode):
             st = sampled_forward(self.pipeline, a, self.model, batch, self.q, self.use_checkpoint,
-                                 side_stream=self.side if _DEBUG == "fork" else None)   # measured: a forked capture is SLOWER here (below)
+                                 side_stream=self.side if _DEBUG == "fork" else None,   # measured: a forked capture is SLOWER here (below)
+                                 prefix=pre)
             if st.cbuf is not None:
                 ops.publish_to_host(st.cbuf, 4, self.epoch_word, self.host_gate)
         pool = c.g1.pool()
@@ -303,9 +333,32 @@ class StepGraphs:
         for i, p in enumerate(self.params):
             p.grad = grads.get(i)
 
-    def forward(self, batch) -> "StepHandle":
+    def replay_g1(self, c):
+        """G0 (if the step has one) and G1 in line on the current stream, G0 with the device's current epoch -- what a replay
+        did before the prefix was split off.  For tools and tests that replay segments by hand."""
+        if c.g0 is not None:
+            main = torch.cuda.current_stream()
+            if self.last_pre is not None:
+                main.wait_event(self.last_pre)
+            self.epoch_pre.copy_(self.epoch_word)
+            c.g0.replay()
+            c.pre_epoch = None
+        c.g1.replay()
+
+    def _issue_prefix(self, c, epoch: int, after) -> None:
+        """G0 of `c` on the prefix stream, for the step whose epoch will be `epoch`, once the main-stream work up to `after` is done."""
+        self.pre_stream.wait_event(after)
+        with torch.cuda.stream(self.pre_stream):
+            self.epoch_pre.fill_(epoch)
+            c.g0.replay()
+            c.pre_event.record(self.pre_stream)
+        c.pre_epoch = epoch
+        self.last_pre = c.pre_event
+
+    def forward(self, batch, next_batch=None) -> "StepHandle":
         """Runs the step up to the gate (E_b > q) or completely (E_b <= q) and returns the handle the trainer
-        finishes the step with: `h.sampled`, `h.cbuf` (gate counts, device int32[5]) and `h.backward(learned)`."""
+        finishes the step with: `h.sampled`, `h.cbuf` (gate counts, device int32[5]) and `h.backward(learned)`.
+        `next_batch` (optional): the batch of the following step; its parameter-independent prefix is issued ahead."""
         key = _batch_key(batch)
         c = self.table.get(key)
         if c is None:                                  # first visit: eager, on the capture stream
@@ -313,8 +366,24 @@ class StepGraphs:
             return _EagerHandle(self, batch)
         if c == "seen":
             c = self.table[key] = self._capture(batch, key)
+        main = torch.cuda.current_stream()
+        if c.g0 is not None:
+            if c.pre_epoch is not None and c.pre_epoch == self.host_epoch:
+                main.wait_event(c.pre_event)           # issued ahead during the previous step
+            else:                                      # in line: after whatever the prefix stream was last given
+                if self.last_pre is not None:
+                    main.wait_event(self.last_pre)
+                self.epoch_pre.copy_(self.epoch_word)
+                c.g0.replay()
+            c.pre_epoch = None
+        if _PREFETCH and next_batch is not None:
+            self.ev_main.record(main)                  # the next partition's prefix may start once everything before THIS G1 is done
         seq0 = int(self.host_gate_np[4])
         c.g1.replay()
+        if _PREFETCH and next_batch is not None:
+            cn = self.table.get(_batch_key(next_batch))
+            if isinstance(cn, _Captured) and cn is not c and cn.g0 is not None:
+                self._issue_prefix(cn, self.host_epoch + 1, self.ev_main)
         return _ReplayHandle(self, c, seq0)
 
     def step(self, batch, epoch=0):
@@ -368,6 +437,7 @@ class _ReplayHandle:
         else:
             c.g2r.replay()
             loss, grads = c.loss_r, c.grads_r
+        sg.host_epoch += 1                             # every backward / unsampled graph ends with sgs_loss_tick
         if sg.dp:
             # gradients + flag word sit in the flat bucket: one all-reduce, then the shared graph that averages and steps
             sg.sync.all_reduce_bucket()

@@ -53,7 +53,21 @@ class SampledForward:
                  "random_out", "cbuf")
 
 
-def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise=None, side_stream=None) -> SampledForward:
+def sampled_prefix(args, batch, q, noise=None):
+    """The parameter-independent head of a sampled step (training_hybrid.py:44-48): the prior-only draw, the CSR of the random
+    graph (squeezed out of the partition's cached CSR) and its unit normalisation.  Depends on the partition and the noise
+    alone, so a captured step can run it for the NEXT partition while the current one is still in flight (stepgraph.py).
+    Returns the draw, or None when the configuration has no prior draw."""
+    if not (args.conditional or args.sparse_edge_mlp):
+        return None
+    noise = noise or {}
+    rs = draw_prior(batch.prob, batch.edge_index, q, noise=noise.get("prior"))
+    graph_r = ops.get_subgraph(batch.edge_index, batch.x.shape[0], rs)
+    ops.gcn_norm(graph_r, None)                                       # cached on the graph: every unweighted layer over it reuses it
+    return rs
+
+
+def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise=None, side_stream=None, prefix=None) -> SampledForward:
     """training_hybrid.py:44-101 (ST 41-90, TP 41-92) up to the gate's inputs: prior draw, pass-1 scores, learned
     draw, encoder over the learned graph, encoder over the random graph, the two correct-counts (device side).
     No host read-back in here, so the whole segment can be captured into a HIP graph (stepgraph.py).
@@ -67,10 +81,9 @@ def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise
     scorer = model.edge_prob_mlp
 
     st.rsei = None
-    if args.conditional or args.sparse_edge_mlp:                      # K0: prior-only draw
-        rs = draw_prior(batch.prob, batch.edge_index, q, noise=noise.get("prior"))
+    if args.conditional or args.sparse_edge_mlp:                      # K0: prior-only draw (`prefix`: already made by sampled_prefix)
+        rs = prefix if prefix is not None else sampled_prefix(args, batch, q, noise)
         st.rsei = rs.edge_index
-        ops.get_subgraph(batch.edge_index, N, rs)                     # CSR of the random graph, squeezed out of the partition's cached CSR
     st.random_out = None
     forked = side_stream is not None and args.conditional and st.rsei is not None
     if forked:
@@ -182,6 +195,23 @@ def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edg
             graphs.release()
 
 
+def _with_lookahead(loader, on: bool):
+    """(batch, following batch or None) pairs; without `on`, (batch, None) and the loader is consumed exactly as before."""
+    if not on:
+        for b in loader:
+            yield b, None
+        return
+    it = iter(loader)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
+
+
 def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, optimizer, criterion,
                 cluster_loader, q, device, mode, use_checkpoint, noise, trace, sync, graphs):
     total_loss = None
@@ -191,7 +221,7 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
     h = None
     if graphs is not None:
         graphs.loss_sum.zero_()
-    for batch in cluster_loader:
+    for batch, batch_after in _with_lookahead(cluster_loader, graphs is not None and mode == 'learned'):
         if not _has_train_nodes(batch):
             continue
         total_update += 1
@@ -200,8 +230,13 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
 
         if mode == 'learned':
             batch = batch.to(device)
-            # `h` (stepgraph.py, opt-in): the same segments replayed from captured HIP graphs instead of launched one by one
-            h = graphs.forward(batch) if graphs is not None else None
+            # `h` (stepgraph.py, opt-in): the same segments replayed from captured HIP graphs instead of launched one by one;
+            # naming the following batch lets it issue that partition's parameter-independent prefix ahead
+            if graphs is not None:
+                nxt = batch_after.to(device) if batch_after is not None and _has_train_nodes(batch_after) else None
+                h = graphs.forward(batch, nxt)
+            else:
+                h = None
             eager_opt = h is None or not h.opt_in_graph       # capturable optimisers are stepped inside the backward graph
             # N > 1 with FusedAdam: a replayed step all-reduces the gradient bucket and replays the optimiser graph inside
             # h.backward(); the "any rank learned" word travels in that bucket and is read on the device

@@ -79,7 +79,7 @@ def test_sampled_replay_matches_eager_recomputation_from_its_own_draws(pipeline)
         params = list(m.parameters())
         seen = []
         for it in range(3):
-            c.g1.replay()
+            sg.replay_g1(c)
             k = {n: (None if t is None else t.clone()) for n, t in c.keep.items()}
             cnt = c.cbuf.tolist()
             seen.append(k["eid"].clone())
@@ -146,7 +146,7 @@ def test_sampled_replay_matches_eager_recomputation_from_its_own_draws(pipeline)
         assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
         e = int(sg.epoch_word.item())
         sg.epoch_word.fill_(e - 2)                     # each iteration replayed G2L and G2R: two epoch ticks after the last G1
-        c.g1.replay()
+        sg.replay_g1(c)
         torch.cuda.synchronize()
         assert torch.equal(c.keep["eid"], seen[2])
     finally:
@@ -215,3 +215,33 @@ def test_graph_mode_with_gat_model_straight_through():
         assert torch.isfinite(p).all(), n
     assert any(not torch.equal(p, before[n]) for n, p in m.named_parameters() if "GAT" in n)
     assert len(m._sgs_stepgraphs.table) == 3
+
+
+def test_prefix_prefetch_on_a_second_stream_changes_nothing(monkeypatch):
+    """The parameter-independent head of a sampled step (prior draw, CSR of the random graph, unit norm) is its own graph G0;
+    with the following batch named it is replayed a step ahead on a second stream.  Same kernels, same epoch values: the
+    run must be bit-identical to the one that replays G0 in line, with dropout on."""
+    import sgs_gnn_amd as S
+    from sgs_gnn_amd import stepgraph
+    crit = torch.nn.CrossEntropyLoss()
+    bs = _batches(S, [5000, 900, 4000, 6000, 4500], n=150)
+    q = 1000
+    results = []
+    for prefetch in (True, False):
+        monkeypatch.setattr(stepgraph, "_PREFETCH", prefetch)
+        torch.manual_seed(3)
+        S.fix_seeds(3)
+        m = S.GNNModel(24, 32, 5, dropout_prob=0.3, edge_mlp_type="GCN").to(DEV)
+        og = S.FusedAdam([p for n, p in m.named_parameters() if "gcn" in n], lr=1e-2)              # main.py:100 (overlap kept)
+        oe = S.FusedAdam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-2)
+        a = _args(sgs_hipgraph=True)
+        rets = [S.train(a, ep, 8, m, og, oe, None, crit, bs, q=q) for ep in range(8)]
+        sg = m._sgs_stepgraphs
+        assert all(c.g0 is not None for c in sg.table.values() if c.sampled)
+        # the host's mirror of the epoch word (what a prefetched G0 is given) agrees with the device
+        assert int(sg.epoch_word.item()) == sg.host_epoch
+        results.append((rets, {n: p.detach().clone() for n, p in m.named_parameters()}))
+    (r_on, p_on), (r_off, p_off) = results
+    assert r_on == r_off
+    for n in p_on:
+        assert torch.equal(p_on[n], p_off[n]), n

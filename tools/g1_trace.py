@@ -25,7 +25,7 @@ c = sg.table[_batch_key(big)]
 cs = sg.table[_batch_key(small)]
 torch.cuda.synchronize()
 import time
-for g in (c.g1, c.g2r, c.g2l, cs.g1):
+for g in ([c.g0] if c.g0 is not None else []) + [c.g1, c.g2r, c.g2l, cs.g1]:
     for _ in range(3):
         torch.cuda.synchronize()
         time.sleep(0.02)        # replays are separated by > 10 ms of idle time in the trace

@@ -11,9 +11,13 @@ for prev, r in zip(rows, rows[1:]):
         segs.append(cur); cur = []
     cur.append(r)
 segs.append(cur)
-segs = segs[-12:]
-names = ["G1 (forward to the gate) big", "G2R (random backward + Adam) big", "G2L (learned backward + 2 Adam) big", "G (unsampled step) small"]
-for gi in range(4):
+names = ["G0 (parameter-independent prefix: prior draw, CSR of the random graph, unit norm) big",
+         "G1 (scores, learned draw, encoders, gate counts) big", "G2R (random backward + Adam) big",
+         "G2L (learned backward + 2 Adam) big", "G (unsampled step) small"]
+if len(segs) < 3 * len(names):       # capture without a prefix graph: no G0 segment
+    names = names[1:]
+segs = segs[-3 * len(names):]
+for gi in range(len(names)):
     seg = segs[gi * 3 + 2]
     t0 = int(seg[0]['Start_Timestamp']); t1 = int(seg[-1]['End_Timestamp'])
     busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in seg)

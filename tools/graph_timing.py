@@ -46,7 +46,7 @@ for bt in pool:
     c = sg.table[_batch_key(bt)]
     E = bt.edge_index.shape[1]
     if c.sampled:
-        rows.append(dict(E=E, g1_us=round(t(c.g1), 1), g2l_us=round(t(c.g2l), 1), g2r_us=round(t(c.g2r), 1),
+        rows.append(dict(E=E, g0_us=round(t(c.g0), 1) if c.g0 is not None else None, g1_us=round(t(c.g1), 1), g2l_us=round(t(c.g2l), 1), g2r_us=round(t(c.g2r), 1),
                          g1_host_launch_us=round(host_us(c.g1), 1), g2r_host_launch_us=round(host_us(c.g2r), 1)))
     else:
         rows.append(dict(E=E, g_us=round(t(c.g1), 1), g_host_launch_us=round(host_us(c.g1), 1)))
