@@ -282,7 +282,7 @@ int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, void* ws, size_
  *   d codes (direct) = reduce(dfeat, dfeat, T = codes, +1, +1);   d U = reduce(dv, dv, NULL, +1, -1).
  * ---------------------------------------------------------------------------------- */
 size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H, int64_t E);   /* E = 0 for the backward core */
-void sgs_edge_score_set_bwd_variant(int variant); /* backward core: -1 / 0 = LDS-tiled (default), 3 = 64-edge streaming loop (A/B: measured slower) */
+void sgs_edge_score_set_bwd_variant(int variant); /* backward core: -1 = automatic (4 at H % 128 == 0 and >= 65 536 active rows, else 0), 0 = LDS-tiled, 3 = 64-edge streaming loop (A/B: measured slower), 4 = bf16x6 loop */
 int sgs_edge_score_bwd_tile(void);              /* active rows per hdz_part row (64) */
 void sgs_edge_score_set_variant(int variant);   /* forward kernel: -1 = automatic (default: when E >= 65 536, 4 if H % 128 == 0 else 3; below that 1),
                                                   * 0 = LDS-tiled, 1 = register-streaming (32-edge wave tile), 2 = weight-stationary

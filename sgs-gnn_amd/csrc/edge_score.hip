@@ -720,7 +720,9 @@ __global__ void __launch_bounds__(kT) pack_w1a_bf16x3(const float* __restrict__ 
 // runs at an effective 2.05 GHz under the counters and the guide's own bf16 loops on random data hold 1.5-1.7 GHz, so it
 // is priced against the clock the chip gives a dense bf16 MFMA stream rather than against stalls.  Counters:
 // SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles x the 8.43 M MFMAs issued, 42 % of the SIMD cycles; no LDS bank conflicts.
-template <int NT, int NW>
+// BWD: the backward core on the same loop (recompute over the active rows, then dv / feat / dz / per-64-edge-tile sums of
+// dz * hidden, exactly what edge_score_kernel<NT, true> produces).
+template <int NT, int NW, bool BWD = false>
 __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(ScoreArgs a, const uint4* __restrict__ Wp16) {
     constexpr int H = 32 * NT;
     constexpr int NPH = H / 16;              // phases: one 16-deep k-chunk each, one barrier per phase
@@ -778,14 +780,21 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
     lstore(wl[0]);
     __syncthreads();
     // one k-chunk: split the (dead afterwards) fp32 features, refill them with chunk `kn_` of the next phase, 6 NT MFMAs
-    auto chunk = [&](const uint4* wcur, Feat& f, int kn_) {
+    auto chunk = [&](const uint4* wcur, Feat& f, int kc_, int kn_) {
         u32x4 F1, F2, F3;
         {
+            const float4 pa = make_float4(f.xa.x * f.ya.x, f.xa.y * f.ya.y, f.xa.z * f.ya.z, f.xa.w * f.ya.w);
+            const float4 pb = make_float4(f.xb.x * f.yb.x, f.xb.y * f.yb.y, f.xb.z * f.yb.z, f.xb.w * f.yb.w);
+            if (BWD && live) {                       // feat[e, k] = x_s[k] x_d[k], k = 16 kc + 8 kh .. + 7, for the weight gradient
+                float4* fo = reinterpret_cast<float4*>(a.feat + r * H + 16 * kc_ + 8 * kh);
+                fo[0] = pa;
+                fo[1] = pb;
+            }
             uint32_t p1, p2, p3;
-            split3(f.xa.x * f.ya.x, f.xa.y * f.ya.y, p1, p2, p3); F1[0] = p1; F2[0] = p2; F3[0] = p3;
-            split3(f.xa.z * f.ya.z, f.xa.w * f.ya.w, p1, p2, p3); F1[1] = p1; F2[1] = p2; F3[1] = p3;
-            split3(f.xb.x * f.yb.x, f.xb.y * f.yb.y, p1, p2, p3); F1[2] = p1; F2[2] = p2; F3[2] = p3;
-            split3(f.xb.z * f.yb.z, f.xb.w * f.yb.w, p1, p2, p3); F1[3] = p1; F2[3] = p2; F3[3] = p3;
+            split3(pa.x, pa.y, p1, p2, p3); F1[0] = p1; F2[0] = p2; F3[0] = p3;
+            split3(pa.z, pa.w, p1, p2, p3); F1[1] = p1; F2[1] = p2; F3[1] = p3;
+            split3(pb.x, pb.y, p1, p2, p3); F1[2] = p1; F2[2] = p2; F3[2] = p3;
+            split3(pb.z, pb.w, p1, p2, p3); F1[3] = p1; F2[3] = p2; F3[3] = p3;
         }
         const bf16x8 f1 = __builtin_bit_cast(bf16x8, F1), f2 = __builtin_bit_cast(bf16x8, F2), f3 = __builtin_bit_cast(bf16x8, F3);
         __builtin_amdgcn_sched_barrier(0);
@@ -827,7 +836,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
         const int pn = ph + 1 < NPH ? ph + 1 : NPH - 1;      // the last phase reloads its own chunks: no branches around the loads
         gload(pn);
         __builtin_amdgcn_sched_barrier(0);           // the next phase's loads are issued FIRST: left alone they sink to the barrier
-        chunk(wcur, fa, pn);
+        chunk(wcur, fa, ph, pn);
         lstore(wnext);
         __syncthreads();
     }
@@ -876,14 +885,60 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
                     const uint32_t draw = (j & 1) ? (bits[j >> 1] >> 16) : (bits[j >> 1] & 0xFFFFu);
                     m = draw >= a.drop_thresh ? m * a.drop_scale : 0.f;
                 }
-                z = fmaf(w4[j], v * m, z);
+                const float hd = v * m;                              // dropout(relu(v))
+                z = fmaf(w4[j], hd, z);
+                if (BWD) acc[t][4 * g4 + j] = hd;                    // kept for the second pass
             }
         }
     }
     z += __shfl_xor(z, 32, 64);
-    if (live && kh == 0) {
-        const float zz = z + a.b2[0];
-        a.p_out[r] = 1.0f / (1.0f + expf(-zz));
+    if (!BWD) {
+        if (live && kh == 0) {
+            const float zz = z + a.b2[0];
+            a.p_out[r] = 1.0f / (1.0f + expf(-zz));
+        }
+        return;
+    }
+    // ---- backward epilogue: dz = gp p (1-p);  dv = dz w2 relu' keep scale;  per-64-edge-tile sums of dz * hidden
+    const float zz = z + a.b2[0];
+    const float pr = 1.0f / (1.0f + expf(-zz));
+    const float dzv = live ? a.gp[r] * pr * (1.0f - pr) : 0.f;                    // 0 on the padding rows of the last tile
+    if (live && kh == 0) a.dz[r] = dzv;
+    const float dscale = a.use_drop ? a.drop_scale : 1.f;
+    // a wave holds 32 edges; a row of hdz_part is 64 (sgs_edge_score_bwd_tile()): waves 2m and 2m+1 meet in LDS (the W
+    // buffers are free: the main loop ended on a barrier)
+    float* hsum = reinterpret_cast<float*>(&wl[0][0]);                            // [NW][H]
+#pragma unroll
+    for (int i = 0; i < 4 * NT; ++i) {
+        if (8 * i < Hrt) {                           // always true: one basic block per step (register budget, as above)
+            const int t = i >> 2, g4 = i & 3;
+            const int hb = 8 * i + 4 * kh;
+            const float4 ww = *reinterpret_cast<const float4*>(&bw[1][hb]);
+            const float w4[4] = {ww.x, ww.y, ww.z, ww.w};
+            float dv4[4], hs[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float hd = acc[t][4 * g4 + j];
+                dv4[j] = dzv * w4[j] * (hd > 0.f ? dscale : 0.f);                 // hd > 0 <=> v > 0 and kept
+                hs[j] = dzv * hd;
+            }
+            if (live) *reinterpret_cast<float4*>(a.dv + r * H + hb) = make_float4(dv4[0], dv4[1], dv4[2], dv4[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float sum = hs[j];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);   // the 32 lanes of this half-wave (equal kh)
+                hs[j] = sum;
+            }
+            if (l31 == 0) *reinterpret_cast<float4*>(hsum + wave * H + hb) = make_float4(hs[0], hs[1], hs[2], hs[3]);
+        }
+    }
+    __syncthreads();
+    // tile (2 blockIdx NW/2 ... ): waves (2m, 2m+1) -> hdz_part row blockIdx * NW/2 + m
+    for (int idx = tid; idx < (NW / 2) * H; idx += TH) {
+        const int m = idx / H, h = idx - m * H;
+        const int64_t prow = static_cast<int64_t>(blockIdx.x) * (NW / 2) + m;
+        if (prow * 64 < a.n) a.hdz[prow * H + h] = hsum[(2 * m) * H + h] + hsum[(2 * m + 1) * H + h];
     }
 }
 
@@ -1244,7 +1299,7 @@ size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H, int64_t E) {
 // 0 = LDS-tiled kernel, 1 = register-streaming kernel, 2 = weight-stationary persistent kernel (forward, H % 64 == 0).
 // A/B switch for benchmarks.  Measured (MI355X, E = 351 194, H = 256, same process): 0 -> 95, 1 -> 100.7, 2 -> 99.5 TFLOP/s;
 // whole-step throughput is equal within noise, so the fastest kernel is the default.
-static int g_bwd_variant = -1;     // -1 / 0: LDS-tiled backward core (default), 3: 64-edge streaming core (A/B only: slower)
+static int g_bwd_variant = -1;     // -1: automatic (4 at H % 128 == 0 and >= 65 536 active rows, else 0); 0: LDS-tiled core; 3: 64-edge streaming core (A/B: slower); 4: bf16x6 loop
 static int g_score_variant = -1;   // -1: automatic (when the launch fills the chip with 128-edge workgroups: 4 if H % 128 == 0, else 3; otherwise 1)
 void sgs_edge_score_set_variant(int v) { g_score_variant = v; }
 void sgs_edge_score_set_bwd_variant(int v) { g_bwd_variant = v; }
@@ -1367,7 +1422,29 @@ int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64
     // (tools/bwd_probe.py) 323 / 656 / 1092 us against 227 / 558 / 997 us for the LDS-tiled core at 100 k / 262 k / 500 k active
     // rows.  The backward is bound by what it writes (dv and feat, 2 KB per row) and the tiled core produces the feature tile
     // in LDS anyway, while the streaming loop has to rebuild row pieces from registers with cross-lane swaps.
-    const bool stream64 = H % 64 == 0 && g_bwd_variant == 3;
+    // automatic: the bf16x6 loop once the launch fills the chip (measured, tools/bwd_probe.py: 160 vs 230 us at 100 k active rows,
+    // 327 vs 574 at 262 k, 618 vs 1009 at 500 k), the LDS-tiled core below that
+    const int bwd_variant = g_bwd_variant >= 0 ? g_bwd_variant : ((H % 128 == 0 && cdiv(n_active, 128) >= 512) ? 4 : 0);
+    if (bwd_variant == 4 && H % 128 == 0 && N > 0) {
+        // the recompute on the bf16x6 loop (forward variant 4): same outputs
+        cv.take<float>(0);
+        cv.take<unsigned int>(64);
+        uint4* Wp16 = cv.take<uint4>(static_cast<size_t>(H) * H * 6 / 16);
+        hipLaunchKernelGGL(pack_w1a_bf16x3, dim3(static_cast<unsigned>(cdiv((H / 16) * (H / 32) * 64, kT))), dim3(kT), 0, stream, W1,
+                           static_cast<int>(H), Wp16);
+        ScoreArgs b{};
+        b.codes = codes; b.U = U; b.src = edge_index; b.dst = edge_index + E; b.active = active_eid; b.n = n_active;
+        b.row_offset = edge_id_offset;
+        b.H = static_cast<int>(H); b.WaT = nullptr; b.b1 = b1; b.w2 = w2; b.b2 = b2;
+        b.drop_scale = 1.0f / (1.0f - p_drop); b.drop_thresh = dropout_thresh(p_drop); b.seed = seed; b.epoch = epoch_ptr(); b.site = site;
+        b.use_drop = p_drop > 0.f; b.gp = grad_p; b.dv = dv; b.hdz = hdz_part; b.dz = dz; b.feat = feat;
+        const dim3 grid(static_cast<unsigned>(cdiv(n_active, 128))), blk(256);
+        if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4, true>), grid, blk, 0, stream, b, Wp16);
+        else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4, true>), grid, blk, 0, stream, b, Wp16);
+        SGS_LAUNCH_OK();
+        return SGS_OK;
+    }
+    const bool stream64 = H % 64 == 0 && bwd_variant == 3;
     if (stream64) {
         const int n_w = static_cast<int>(cdiv(H * H, kT));
         hipLaunchKernelGGL(pack_stream_operands, dim3(static_cast<unsigned>(n_w + cdiv(N * H, kT))), dim3(kT), 0, stream, W1,

@@ -135,10 +135,11 @@ def test_bf16x6_split_is_fp32_faithful(ops, H):
     assert err[4] <= 2 * err[3] + 6e-8
 
 
+@pytest.mark.parametrize("other", [3, 4])
 @pytest.mark.parametrize("H,p", [(256, 0.3), (128, 0.0)])
-def test_backward_core_stream64_matches_lds_tiled(ops, H, p):
-    """The backward core on the 64-edge streaming loop (an A/B option, forced here) against the LDS-tiled core:
-    dv, feat, dz and the column sums of the per-tile dz * hidden partials."""
+def test_backward_core_stream64_matches_lds_tiled(ops, H, p, other):
+    """The backward core on the 64-edge streaming loop (3) and on the bf16x6 loop (4), forced here, against the LDS-tiled
+    core: dv, feat, dz and the column sums of the per-tile dz * hidden partials."""
     import sgs_gnn_amd as S
     L = S._lib.lib()
     N, E, n = 1013, 60000, 40003
@@ -153,7 +154,7 @@ def test_backward_core_stream64_matches_lds_tiled(ops, H, p):
     tile = L.sgs_edge_score_bwd_tile()
     outs = []
     try:
-        for variant in (0, 3):
+        for variant in (0, other):
             L.sgs_edge_score_set_bwd_variant(variant)
             dv, feat = torch.full((n, H), float("nan"), device=DEV), torch.full((n, H), float("nan"), device=DEV)
             hdz = torch.full(((n + tile - 1) // tile, H), float("nan"), device=DEV)

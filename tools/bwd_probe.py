@@ -1,4 +1,4 @@
-"""A/B of the scorer backward core: LDS-tiled (0) vs 64-edge streaming loop (3), by active-set size."""
+"""A/B of the scorer backward core: LDS-tiled (0) vs 64-edge streaming loop (3) vs bf16x6 loop (4), by active-set size."""
 import os, sys, json
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,7 +21,7 @@ for n in (100000, 262144, 500000):
     dv, feat, dz = torch.empty(n, H, device=DEV), torch.empty(n, H, device=DEV), torch.empty(n, device=DEV)
     hdz = torch.empty((n + tile - 1) // tile, H, device=DEV)
     ws = ops.workspace(L.sgs_edge_score_workspace_bytes(N, H, 0), codes.device)
-    for variant in (0, 3):
+    for variant in (0, 3, 4):
         L.sgs_edge_score_set_bwd_variant(variant)
         def f():
             S._lib.check(L.sgs_edge_score_bwd_core(codes.data_ptr(), U.data_ptr(), N, H, ei.data_ptr(), E, 0, eid.data_ptr(), n, gp.data_ptr(),
