@@ -299,6 +299,13 @@ int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64
                             const float* W1, const float* b1, const float* w2, const float* b2, float p_drop,
                             uint64_t seed, uint32_t site, float* dv, float* hdz_part, float* dz, float* feat, void* ws,
                             size_t ws_bytes, sgs_stream_t stream);
+/* dfeat [n,H] = dv [n,H] . W1[:, :H]: the gradient wrt the Hadamard features x_s * x_d that the scorer backward (model.py:29-34 under
+ * autograd) forms from sgs_edge_score_bwd_core's dv.  The forward's bf16x6 loop as a row GEMM (fp32-faithful, see
+ * sgs_edge_score_set_variant); H = 128 or 256 only -- ask sgs_edge_score_bwd_dfeat_supported, other sizes use a library GEMM.
+ * Workspace: sgs_edge_score_workspace_bytes(0, H, 0). */
+int sgs_edge_score_bwd_dfeat_supported(int64_t H);
+int sgs_edge_score_bwd_dfeat(const float* dv, int64_t n, int64_t H, const float* W1, float* dfeat, void* ws, size_t ws_bytes,
+                             sgs_stream_t stream);
 int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, int64_t N, int64_t H, int64_t nnz,
                         const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid, const int32_t* out_ptr,
                         const int32_t* out_dst, const int32_t* out_eid, float sign_out, float sign_in, float* out,

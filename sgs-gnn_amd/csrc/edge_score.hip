@@ -693,6 +693,7 @@ __device__ __forceinline__ void split3(float a, float b, uint32_t& p1, uint32_t&
     p3 = pk_bf16(sa, sb);
 }
 
+template <bool TRANSPOSED = false>      // TRANSPOSED: the pieces of W1a^T (row h of the operand = column h of W1a): the row-GEMM mode's operand
 __global__ void __launch_bounds__(kT) pack_w1a_bf16x3(const float* __restrict__ W1, int H, uint4* __restrict__ Wp16) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;       // one (kc, t, lane)
     const int NTl = H / 32;
@@ -701,10 +702,13 @@ __global__ void __launch_bounds__(kT) pack_w1a_bf16x3(const float* __restrict__ 
     const int64_t rest = i >> 6;
     const int t = static_cast<int>(rest % NTl), kc = static_cast<int>(rest / NTl);
     const int h = 32 * t + (lane & 31), k0 = 16 * kc + 8 * (lane >> 5);
-    const float* w = W1 + static_cast<int64_t>(h) * 2 * H + k0;
     uint32_t p[3][4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) split3(w[2 * m], w[2 * m + 1], p[0][m], p[1][m], p[2][m]);
+    for (int m = 0; m < 4; ++m) {
+        const float w0 = TRANSPOSED ? W1[static_cast<int64_t>(k0 + 2 * m) * 2 * H + h] : W1[static_cast<int64_t>(h) * 2 * H + k0 + 2 * m];
+        const float w1 = TRANSPOSED ? W1[static_cast<int64_t>(k0 + 2 * m + 1) * 2 * H + h] : W1[static_cast<int64_t>(h) * 2 * H + k0 + 2 * m + 1];
+        split3(w0, w1, p[0][m], p[1][m], p[2][m]);
+    }
     uint4* o = Wp16 + (static_cast<int64_t>(kc) * NTl + t) * 3 * 64 + lane;
 #pragma unroll
     for (int c = 0; c < 3; ++c) o[c * 64] = make_uint4(p[c][0], p[c][1], p[c][2], p[c][3]);
@@ -720,10 +724,14 @@ __global__ void __launch_bounds__(kT) pack_w1a_bf16x3(const float* __restrict__ 
 // runs at an effective 2.05 GHz under the counters and the guide's own bf16 loops on random data hold 1.5-1.7 GHz, so it
 // is priced against the clock the chip gives a dense bf16 MFMA stream rather than against stalls.  Counters:
 // SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles x the 8.43 M MFMAs issued, 42 % of the SIMD cycles; no LDS bank conflicts.
-// BWD: the backward core on the same loop (recompute over the active rows, then dv / feat / dz / per-64-edge-tile sums of
+// MODE 1: the backward core on the same loop (recompute over the active rows, then dv / feat / dz / per-64-edge-tile sums of
 // dz * hidden, exactly what edge_score_kernel<NT, true> produces).
-template <int NT, int NW, bool BWD = false>
+// MODE 2: the loop as a row GEMM, out[r, :] = in[r, :] . M for a dense [n, H] input (a.codes -> a.feat): the backward's
+// dfeat = dv W1a, with `Wp16` packed from the TRANSPOSED matrix (pack_w1a_bf16x3<true>); no gather, no product, the
+// accumulators are the result.
+template <int NT, int NW, int MODE = 0>
 __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(ScoreArgs a, const uint4* __restrict__ Wp16) {
+    constexpr bool BWD = MODE == 1, GEMM = MODE == 2;
     constexpr int H = 32 * NT;
     constexpr int NPH = H / 16;              // phases: one 16-deep k-chunk each, one barrier per phase
     constexpr int CH = NT * 3 * 64;          // 16-byte words per k-chunk of W1a (all hidden units, three pieces)
@@ -734,18 +742,20 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
     __shared__ __attribute__((aligned(16))) float bw[2][H];          // b1, w2 for the epilogue
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = lane >> 5, l31 = lane & 31;
-    for (int i = tid; i < H; i += TH) { bw[0][i] = a.b1[i]; bw[1][i] = a.w2[i]; }    // (visible after the first barrier below)
+    if (!GEMM)
+        for (int i = tid; i < H; i += TH) { bw[0][i] = a.b1[i]; bw[1][i] = a.w2[i]; }    // (visible after the first barrier below)
     const int64_t row0 = static_cast<int64_t>(blockIdx.x) * (32 * NW);
     const int64_t r = row0 + 32 * wave + l31;
     const bool live = r < a.n;
     int s = 0, d = 0;
     int64_t eg_id = 0;
-    if (live) {
+    if (live && !GEMM) {
         eg_id = a.active ? a.active[r] : r;
         s = static_cast<int>(a.src[eg_id]);
         d = static_cast<int>(a.dst[eg_id]);
     }
-    const float4* xp = reinterpret_cast<const float4*>(a.codes + static_cast<int64_t>(s) * H + 8 * kh);
+    const int64_t xrow = GEMM ? (live ? r : 0) : static_cast<int64_t>(s);          // MODE 2 reads its own row (row 0 on the padding rows)
+    const float4* xp = reinterpret_cast<const float4*>(a.codes + xrow * H + 8 * kh);
     const float4* yp = reinterpret_cast<const float4*>(a.codes + static_cast<int64_t>(d) * H + 8 * kh);
 
     f32x16 acc[NT];
@@ -771,7 +781,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
     };
     auto fload = [&](int kc, Feat& f) {
         f.xa = xp[4 * kc]; f.xb = xp[4 * kc + 1];
-        f.ya = yp[4 * kc]; f.yb = yp[4 * kc + 1];
+        if (!GEMM) { f.ya = yp[4 * kc]; f.yb = yp[4 * kc + 1]; }
     };
     struct WF { uint4 q1, q2, q3; };
     Feat fa;
@@ -783,8 +793,8 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
     auto chunk = [&](const uint4* wcur, Feat& f, int kc_, int kn_) {
         u32x4 F1, F2, F3;
         {
-            const float4 pa = make_float4(f.xa.x * f.ya.x, f.xa.y * f.ya.y, f.xa.z * f.ya.z, f.xa.w * f.ya.w);
-            const float4 pb = make_float4(f.xb.x * f.yb.x, f.xb.y * f.yb.y, f.xb.z * f.yb.z, f.xb.w * f.yb.w);
+            const float4 pa = GEMM ? f.xa : make_float4(f.xa.x * f.ya.x, f.xa.y * f.ya.y, f.xa.z * f.ya.z, f.xa.w * f.ya.w);
+            const float4 pb = GEMM ? f.xb : make_float4(f.xb.x * f.yb.x, f.xb.y * f.yb.y, f.xb.z * f.yb.z, f.xb.w * f.yb.w);
             if (BWD && live) {                       // feat[e, k] = x_s[k] x_d[k], k = 16 kc + 8 kh .. + 7, for the weight gradient
                 float4* fo = reinterpret_cast<float4*>(a.feat + r * H + 16 * kc_ + 8 * kh);
                 fo[0] = pa;
@@ -839,6 +849,15 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
         chunk(wcur, fa, ph, pn);
         lstore(wnext);
         __syncthreads();
+    }
+    if constexpr (GEMM) {                            // out[r, 8 i + 4 kh + j] = accumulator register 4 g4 + j of tile t (i = 4 t + g4)
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 4 * NT; ++i)
+                *reinterpret_cast<float4*>(a.feat + r * H + 8 * i + 4 * kh) =
+                    make_float4(acc[i >> 2][4 * (i & 3)], acc[i >> 2][4 * (i & 3) + 1], acc[i >> 2][4 * (i & 3) + 2], acc[i >> 2][4 * (i & 3) + 3]);
+        }
+        return;
     }
 
     // ---- epilogue (as variants B / D): hidden unit 8 i + j + 4 kh for step i = 4 t + g4; the wave holds every hidden unit.
@@ -1360,7 +1379,7 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
         cv.take<float>(2 * static_cast<size_t>(E));
         cv.take<unsigned int>(64);
         uint4* Wp16 = cv.take<uint4>(static_cast<size_t>(H) * H * 6 / 16);
-        hipLaunchKernelGGL(pack_w1a_bf16x3, dim3(static_cast<unsigned>(cdiv((H / 16) * (H / 32) * 64, kT))), dim3(kT), 0, stream, W1,
+        hipLaunchKernelGGL(pack_w1a_bf16x3<false>, dim3(static_cast<unsigned>(cdiv((H / 16) * (H / 32) * 64, kT))), dim3(kT), 0, stream, W1,
                            static_cast<int>(H), Wp16);
         const dim3 grid(static_cast<unsigned>(cdiv(E, 128))), blk(256);       // 4 waves x 32 edges; two workgroups per CU
         if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4>), grid, blk, 0, stream, a, Wp16);
@@ -1430,7 +1449,7 @@ int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64
         cv.take<float>(0);
         cv.take<unsigned int>(64);
         uint4* Wp16 = cv.take<uint4>(static_cast<size_t>(H) * H * 6 / 16);
-        hipLaunchKernelGGL(pack_w1a_bf16x3, dim3(static_cast<unsigned>(cdiv((H / 16) * (H / 32) * 64, kT))), dim3(kT), 0, stream, W1,
+        hipLaunchKernelGGL(pack_w1a_bf16x3<false>, dim3(static_cast<unsigned>(cdiv((H / 16) * (H / 32) * 64, kT))), dim3(kT), 0, stream, W1,
                            static_cast<int>(H), Wp16);
         ScoreArgs b{};
         b.codes = codes; b.U = U; b.src = edge_index; b.dst = edge_index + E; b.active = active_eid; b.n = n_active;
@@ -1439,8 +1458,8 @@ int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64
         b.drop_scale = 1.0f / (1.0f - p_drop); b.drop_thresh = dropout_thresh(p_drop); b.seed = seed; b.epoch = epoch_ptr(); b.site = site;
         b.use_drop = p_drop > 0.f; b.gp = grad_p; b.dv = dv; b.hdz = hdz_part; b.dz = dz; b.feat = feat;
         const dim3 grid(static_cast<unsigned>(cdiv(n_active, 128))), blk(256);
-        if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4, true>), grid, blk, 0, stream, b, Wp16);
-        else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4, true>), grid, blk, 0, stream, b, Wp16);
+        if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4, 1>), grid, blk, 0, stream, b, Wp16);
+        else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4, 1>), grid, blk, 0, stream, b, Wp16);
         SGS_LAUNCH_OK();
         return SGS_OK;
     }
@@ -1467,6 +1486,35 @@ int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64
         return SGS_OK;
     }
     return launch_score<true>(a, stream);
+}
+
+/* dfeat [n,H] = dv [n,H] . W1[:, :H]  (the scorer backward's gradient wrt the Hadamard features).  The bf16x6 loop as a row GEMM at
+ * H = 128 or 256 (sgs_edge_score_bwd_dfeat_supported; other sizes: the caller uses a library GEMM). */
+int sgs_edge_score_bwd_dfeat_supported(int64_t H) { return (H == 128 || H == 256) ? 1 : 0; }
+
+int sgs_edge_score_bwd_dfeat(const float* dv, int64_t n, int64_t H, const float* W1, float* dfeat, void* ws, size_t ws_bytes,
+                             sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(n >= 0 && H > 0, SGS_EINVAL, "sgs_edge_score_bwd_dfeat: bad sizes");
+    SGS_REQUIRE(sgs_edge_score_bwd_dfeat_supported(H), SGS_EINVAL, "sgs_edge_score_bwd_dfeat: H=%lld unsupported (128 or 256)", (long long)H);
+    if (n == 0) return SGS_OK;
+    SGS_REQUIRE(dv && W1 && dfeat, SGS_EINVAL, "sgs_edge_score_bwd_dfeat: null pointer");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_workspace_bytes(0, H, 0), SGS_EWORKSPACE, "sgs_edge_score_bwd_dfeat: workspace too small");
+    Carver cv(ws);
+    cv.take<float>(static_cast<size_t>(H) * H);
+    cv.take<float>(0);
+    cv.take<float>(0);
+    cv.take<unsigned int>(64);
+    uint4* Wp16 = cv.take<uint4>(static_cast<size_t>(H) * H * 6 / 16);
+    hipLaunchKernelGGL(pack_w1a_bf16x3<true>, dim3(static_cast<unsigned>(cdiv((H / 16) * (H / 32) * 64, kT))), dim3(kT), 0, stream, W1,
+                       static_cast<int>(H), Wp16);
+    ScoreArgs a{};
+    a.codes = dv; a.n = n; a.H = static_cast<int>(H); a.feat = dfeat;
+    const dim3 grid(static_cast<unsigned>(cdiv(n, 128))), blk(256);
+    if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4, 2>), grid, blk, 0, stream, a, Wp16);
+    else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4, 2>), grid, blk, 0, stream, a, Wp16);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
 }
 
 int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, int64_t N, int64_t H, int64_t nnz,

@@ -484,9 +484,16 @@ class _EdgeScore(torch.autograd.Function):
                                                  _ptr(W1), _ptr(b1), _ptr(w2), _ptr(b2), ctx.p, ctx.seed, ctx.site, _ptr(dv),
                                                  _ptr(hdz), _ptr(dz), _ptr(feat), ws.data_ptr(), ws.numel(), _stream()),
                        "sgs_edge_score_bwd_core")
-        # dfeat = dv W1a as F.linear with a contiguous W1a^T: the vendor GEMM runs that form at 110 TFLOP/s (85 with the strided view)
-        W1a_t = W1[:, :H].t().contiguous()
-        dfeat = torch.nn.functional.linear(dv, W1a_t)          # [n,H]
+        if n >= 65536 and L.sgs_edge_score_bwd_dfeat_supported(H):
+            # dfeat = dv W1a on the forward's bf16x6 loop as a row GEMM (fp32-faithful): ~75 us at 100 k rows against 122 us below
+            dfeat = torch.empty(n, H, **f32)
+            wsd = workspace(L.sgs_edge_score_workspace_bytes(0, H, 0), dev)
+            _lib.check(L.sgs_edge_score_bwd_dfeat(_ptr(dv), n, H, _ptr(W1), _ptr(dfeat), wsd.data_ptr(), wsd.numel(), _stream()),
+                       "sgs_edge_score_bwd_dfeat")
+        else:
+            # as F.linear with a contiguous W1a^T: the vendor GEMM runs that form at 110 TFLOP/s (85 with the strided view)
+            W1a_t = W1[:, :H].t().contiguous()
+            dfeat = torch.nn.functional.linear(dv, W1a_t)          # [n,H]
         # dW1a = dv^T feat (K = n rows): sgs_gemm_tn's tall-K kernel; the vendor GEMM picks a 42 TFLOP/s kernel for this shape
         dW1 = torch.zeros_like(W1)
         dW1a = torch.empty(H, H, dtype=torch.float32, device=dev)

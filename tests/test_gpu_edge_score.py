@@ -173,3 +173,28 @@ def test_backward_core_stream64_matches_lds_tiled(ops, H, p, other):
     torch.testing.assert_close(dz1, dz0, rtol=2e-4, atol=1e-6)
     torch.testing.assert_close(dv1, dv0, rtol=2e-4, atol=1e-6)
     torch.testing.assert_close(h1, h0, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("H,n", [(256, 100003), (128, 70000), (256, 65)])
+def test_bwd_dfeat_row_gemm_is_fp32_faithful(ops, H, n):
+    """dfeat = dv . W1[:, :H] on the bf16x6 loop (row-GEMM mode): error against fp64 no larger than a plain fp32 GEMM's."""
+    import sgs_gnn_amd as S
+    L = S._lib.lib()
+    assert L.sgs_edge_score_bwd_dfeat_supported(H) == 1 and L.sgs_edge_score_bwd_dfeat_supported(64) == 0
+    g = torch.Generator().manual_seed(H + n)
+    dv = (torch.randn(n, H, generator=g) * torch.exp(torch.randn(n, 1, generator=g))).to(DEV)
+    dv[::7] = 0                                                          # rows the gate / ReLU zeroed
+    W1 = (torch.randn(H, 2 * H, generator=g) / (2 * H) ** 0.5).to(DEV)
+    out = torch.full((n, H), float("nan"), device=DEV)
+    ws = ops.workspace(L.sgs_edge_score_workspace_bytes(0, H, 0), dv.device)
+    S._lib.check(L.sgs_edge_score_bwd_dfeat(dv.data_ptr(), n, H, W1.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()),
+                 "bwd_dfeat")
+    torch.cuda.synchronize()
+    ref64 = dv.double() @ W1[:, :H].double()
+    ref32 = dv @ W1[:, :H]
+    scale = float(ref64.abs().max())
+    e_new = float((out.double() - ref64).abs().max()) / scale
+    e_lib = float((ref32.double() - ref64).abs().max()) / scale
+    print("max err / max|ref|: bf16x6", e_new, "library fp32 GEMM", e_lib)
+    assert torch.isfinite(out).all()
+    assert e_new <= 2 * e_lib + 1e-7
