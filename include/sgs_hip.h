@@ -400,6 +400,7 @@ int sgs_gemm_tn(const float* A, const float* B, int64_t K, int64_t M, int64_t N,
                 sgs_stream_t stream);
 /* Same product with the column sums of A as a by-product (colsum_A [M]; d b1 = colsum(dv) of the scorer's backward rides
  * on d W1a = dv^T feat): only for the shapes the tall-K kernel serves with a split -- ask sgs_gemm_tn_can_colsum first. */
+void sgs_gemm_tn_set_tall_variant(int variant);   /* tall-K shapes (K >= 8192): 1 / -1 = bf16x6 kernel (default; fp32-faithful, see sgs_edge_score_set_variant), 0 = fp32-MFMA kernel */
 int sgs_gemm_tn_can_colsum(int64_t K, int64_t M, int64_t N);
 int sgs_gemm_tn_colsum(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, float* colsum_A, void* ws,
                        size_t ws_bytes, sgs_stream_t stream);

@@ -675,24 +675,6 @@ __global__ void __launch_bounds__(kT, 2) edge_score_stream64_kernel(ScoreArgs a,
 //     fp32 of each endpoint's row of the plain node codes (two 16-byte loads per endpoint per chunk, no re-layout), multiplied
 //     and split in registers (52 vector instructions per 48 MFMAs), and the fc2 reduction never leaves the wave.
 // Requires H % 128 == 0.
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
-
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {       // (bf16(a) low, bf16(b) high), round to nearest even
-    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    const f32x2_t v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
-}
-// (a, b) -> packed pieces p1, p2, p3 with a = a1 + a2 + a3 (same for b)
-__device__ __forceinline__ void split3(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
-    p1 = pk_bf16(a, b);
-    const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xFFFF0000u);
-    p2 = pk_bf16(ra, rb);
-    const float sa = ra - __uint_as_float(p2 << 16), sb = rb - __uint_as_float(p2 & 0xFFFF0000u);
-    p3 = pk_bf16(sa, sb);
-}
-
 template <bool TRANSPOSED = false>      // TRANSPOSED: the pieces of W1a^T (row h of the operand = column h of W1a): the row-GEMM mode's operand
 __global__ void __launch_bounds__(kT) pack_w1a_bf16x3(const float* __restrict__ W1, int H, uint4* __restrict__ Wp16) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;       // one (kc, t, lane)

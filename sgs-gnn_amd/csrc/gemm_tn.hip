@@ -150,6 +150,109 @@ __global__ void __launch_bounds__(64) gemm_tn_tall_tile(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The tall-K product on the bf16 matrix pipe (bf16x6, see sgs_common.h / edge_score.hip): same 128 x 64 wave tile, same
+// interleaved row / column assignment and the same split-K slabs as gemm_tn_tall_tile, but a step is 16 rows of K: lane
+// (l31, g) loads rows k + 8 g + j (j = 0..7) -- eight 16-byte pieces of A (its element of four M-tiles each) and eight 8-byte
+// pieces of B (two N-tiles) -- splits the 48 values into three bf16 pieces each and issues 8 tiles x 6 products of
+// v_mfma_f32_32x32x16_bf16.  fp32-faithful like the scorer loop; the VALU work (264 instructions per 48 MFMAs) is at the
+// budget the matrix pipe leaves, so the kernel runs one wave per SIMD with the next step's loads in flight.
+__global__ void __launch_bounds__(64) gemm_tn_tall_bf16x6(const float* __restrict__ A, const float* __restrict__ B, int64_t K, int M, int N,
+                                                         int ksplit, float* __restrict__ slab, float* __restrict__ cpart) {
+    const int lane = threadIdx.x, g = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 64, s = blockIdx.z;
+    const int ia = m0 + 4 * l31, jb = n0 + 2 * l31;
+    const bool aok = ia < M, bok = jb < N;
+    const int64_t per = ((K + ksplit - 1) / ksplit + 15) & ~int64_t(15);   // slice length: a whole number of 16-row steps
+    const int64_t k0 = s * per, k1 = (k0 + per < K) ? k0 + per : K;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float2 z2 = make_float2(0.f, 0.f);
+    const bool want_cs = cpart != nullptr && blockIdx.y == 0;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    struct Raw { float4 a[8]; float2 b[8]; };
+    auto load = [&](int64_t k, Raw& r) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t kk = k + 8 * g + j;
+            const bool in = kk < k1;
+            r.a[j] = (aok && in) ? *reinterpret_cast<const float4*>(A + kk * M + ia) : z4;
+            r.b[j] = (bok && in) ? *reinterpret_cast<const float2*>(B + kk * N + jb) : z2;
+        }
+    };
+    auto mma = [&](const Raw& r) {
+        if (want_cs) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { cs[0] += r.a[j].x; cs[1] += r.a[j].y; cs[2] += r.a[j].z; cs[3] += r.a[j].w; }
+        }
+        u32x4 Bp[2][3];
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float e0 = w == 0 ? r.b[2 * m].x : r.b[2 * m].y, e1 = w == 0 ? r.b[2 * m + 1].x : r.b[2 * m + 1].y;
+                uint32_t p1, p2, p3;
+                split3(e0, e1, p1, p2, p3);
+                Bp[w][0][m] = p1; Bp[w][1][m] = p2; Bp[w][2][m] = p3;
+            }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            u32x4 Ap[3];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float4 lo = r.a[2 * m], hi = r.a[2 * m + 1];
+                const float e0 = t == 0 ? lo.x : t == 1 ? lo.y : t == 2 ? lo.z : lo.w;
+                const float e1 = t == 0 ? hi.x : t == 1 ? hi.y : t == 2 ? hi.z : hi.w;
+                uint32_t p1, p2, p3;
+                split3(e0, e1, p1, p2, p3);
+                Ap[0][m] = p1; Ap[1][m] = p2; Ap[2][m] = p3;
+            }
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, Ap[0]), a2 = __builtin_bit_cast(bf16x8, Ap[1]), a3 = __builtin_bit_cast(bf16x8, Ap[2]);
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, Bp[w][0]), b2 = __builtin_bit_cast(bf16x8, Bp[w][1]), b3 = __builtin_bit_cast(bf16x8, Bp[w][2]);
+                acc[t][w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t][w], 0, 0, 0);     // smallest terms first
+                acc[t][w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t][w], 0, 0, 0);
+                acc[t][w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t][w], 0, 0, 0);
+                acc[t][w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t][w], 0, 0, 0);
+                acc[t][w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t][w], 0, 0, 0);
+                acc[t][w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t][w], 0, 0, 0);
+            }
+        }
+    };
+    Raw r0, r1;
+    load(k0, r0);
+#pragma unroll 1
+    for (int64_t k = k0; k < k1; k += 32) {
+        load(k + 16, r1);                                   // rows past k1 load zeros
+        mma(r0);
+        load(k + 32, r0);
+        mma(r1);
+    }
+    if (want_cs) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) cs[t] += __shfl_xor(cs[t], 32, 64);          // the two 8-row groups of every step
+        if (g == 0 && aok) *reinterpret_cast<float4*>(cpart + static_cast<int64_t>(s) * M + ia) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+    }
+    float* out = slab + static_cast<int64_t>(s) * M * N;
+    // accumulator register r of tile (t, w): row m0 + 4 ((r & 3) + 8 (r >> 2) + 4 g) + t, column n0 + 2 l31 + w
+    if (bok) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * g) + t;
+                if (row < M) *reinterpret_cast<float2*>(out + static_cast<int64_t>(row) * N + jb) = make_float2(acc[t][0][r], acc[t][1][r]);
+            }
+    }
+}
+
 inline bool use_tall(int64_t K, int64_t M, int64_t N) { return K >= kTallK && M % 4 == 0 && N % 2 == 0; }
 inline int pick_ksplit_tall(int64_t K, int64_t M, int64_t N) {
     const int64_t tiles = cdiv(M, 128) * cdiv(N, 64);
@@ -181,6 +284,10 @@ size_t sgs_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N) {
 
 static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, float* colsum_A, void* ws,
                         size_t ws_bytes, hipStream_t stream);
+// tall-K shapes: 1 = bf16x6 kernel (default; measured 147 vs 175 us incl. the 34 us slab reduction at K = 100 000, M = N = 256: the
+// operand splits, 264 vector instructions per 48 MFMAs, are at the budget the matrix pipe leaves), 0 = fp32-MFMA kernel
+static int g_tall_bf16x6 = 1;
+void sgs_gemm_tn_set_tall_variant(int v) { g_tall_bf16x6 = v < 0 ? 1 : (v ? 1 : 0); }
 
 int sgs_gemm_tn(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, void* ws, size_t ws_bytes,
                 sgs_stream_t stream_) {
@@ -207,7 +314,10 @@ static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, in
     float* slab = cv.take<float>(static_cast<size_t>(ks) * M * N);
     float* cpart = cv.take<float>(static_cast<size_t>(ks) * M);
     float* dst = ks == 1 ? C : slab;
-    if (use_tall(K, M, N))
+    if (use_tall(K, M, N) && g_tall_bf16x6)
+        hipLaunchKernelGGL(gemm_tn_tall_bf16x6, dim3(cdiv(M, 128), cdiv(N, 64), ks), dim3(64), 0, stream, A, B, K, static_cast<int>(M),
+                           static_cast<int>(N), ks, dst, colsum_A ? cpart : static_cast<float*>(nullptr));
+    else if (use_tall(K, M, N))
         hipLaunchKernelGGL(gemm_tn_tall_tile, dim3(cdiv(M, 128), cdiv(N, 64), ks), dim3(64), 0, stream, A, B, K, static_cast<int>(M),
                            static_cast<int>(N), ks, dst, colsum_A ? cpart : static_cast<float*>(nullptr));
     else

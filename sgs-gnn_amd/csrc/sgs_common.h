@@ -120,6 +120,28 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return r;  // valid in every thread
 }
 
+// ---------------------------------------------------------------- fp32 on the bf16 matrix pipe (bf16x6)
+// v = v1 + v2 + v3 exactly, three bf16 pieces by round-to-nearest residuals; users: csrc/edge_score.hip (the scheme and its
+// error bound are described there), csrc/gemm_tn.hip.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {       // (bf16(a) low, bf16(b) high), round to nearest even
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+// (a, b) -> packed pieces p1, p2, p3 with a = a1 + a2 + a3 (same for b)
+__device__ __forceinline__ void split3(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    p1 = pk_bf16(a, b);
+    const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xFFFF0000u);
+    p2 = pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(p2 << 16), sb = rb - __uint_as_float(p2 & 0xFFFF0000u);
+    p3 = pk_bf16(sa, sb);
+}
+
+
 // ---------------------------------------------------------------- counter-based RNG
 // Philox4x32-10 (Salmon et al. 2011).  Integer-only, so host restatements reproduce it exactly.
 struct Philox4 {

@@ -164,6 +164,41 @@ def test_gemm_tn_weight_gradient(pkg, K, M, N):
     assert float((xd.grad.cpu().double() - refx).abs().max()) / (float(refx.abs().max()) + 1e-12) < 1e-5
 
 
+@pytest.mark.parametrize("K,M,N", [(100003, 256, 256), (20011, 256, 256), (9001, 132, 70), (8192, 4, 2)])
+def test_gemm_tn_tall_bf16x6_is_fp32_faithful(pkg, K, M, N):
+    """The tall-K product on the bf16 matrix pipe (six bf16 MFMAs per fp32 product over exact 3-way splits) against fp64, next to
+    the fp32-MFMA kernel: the error must be of the same size; column sums of A as a by-product either way."""
+    L = pkg._lib.lib()
+    g = torch.Generator().manual_seed(K + M)
+    A = (torch.randn(K, M, generator=g) * torch.exp(torch.randn(K, 1, generator=g))).to(DEV)
+    A[::5] = 0
+    B = torch.relu(torch.randn(K, N, generator=g)).to(DEV)
+    ref = A.double().t() @ B.double()
+    refc = A.double().sum(0)
+    ws = pkg.ops.workspace(L.sgs_gemm_tn_workspace_bytes(K, M, N), A.device)
+    err, errc = {}, {}
+    try:
+        for v in (0, 1):
+            L.sgs_gemm_tn_set_tall_variant(v)
+            C = torch.full((M, N), float("nan"), device=DEV)
+            cs = torch.full((M,), float("nan"), device=DEV)
+            if L.sgs_gemm_tn_can_colsum(K, M, N):
+                pkg._lib.check(L.sgs_gemm_tn_colsum(A.data_ptr(), B.data_ptr(), K, M, N, C.data_ptr(), cs.data_ptr(), ws.data_ptr(),
+                                                    ws.numel(), pkg.ops._stream()), "sgs_gemm_tn_colsum")
+                errc[v] = float((cs.double() - refc).abs().max()) / float(refc.abs().max())
+            else:
+                pkg._lib.check(L.sgs_gemm_tn(A.data_ptr(), B.data_ptr(), K, M, N, C.data_ptr(), ws.data_ptr(), ws.numel(),
+                                             pkg.ops._stream()), "sgs_gemm_tn")
+            torch.cuda.synchronize()
+            err[v] = float((C.double() - ref).abs().max()) / float(ref.abs().max())
+    finally:
+        L.sgs_gemm_tn_set_tall_variant(-1)
+    print("max err / max|ref|:", err, "colsum:", errc)
+    assert err[1] <= 2 * err[0] + 1e-7 and err[1] < 6e-6
+    for v in errc:
+        assert errc[v] < 2e-6
+
+
 def test_gemm_tn_tall_with_column_sums(pkg):
     """sgs_gemm_tn_colsum: dW = A^T B on the tall-K kernel with colsum(A) as a by-product (d b1 of the scorer backward)."""
     L = pkg._lib.lib()

@@ -28,5 +28,8 @@ C = torch.empty(H, H, device=dev)
 ws = S.ops.workspace(L.sgs_gemm_tn_workspace_bytes(q, H, H), dv.device)
 def own():
     S._lib.check(L.sgs_gemm_tn(dv.data_ptr(), feat.data_ptr(), q, H, H, C.data_ptr(), ws.data_ptr(), ws.numel(), S.ops._stream()), "gemm_tn")
-us = t(own)
-print(f"{'sgs_gemm_tn(dv, feat)':32s} {us:8.1f} us  {fl / us / 1e6:6.1f} TFLOP/s   max err vs torch {float((C - dv.t() @ feat).abs().max()):.3e}")
+for v, nm in ((0, "sgs_gemm_tn(dv, feat) fp32 MFMA"), (1, "sgs_gemm_tn(dv, feat) bf16x6")):
+    L.sgs_gemm_tn_set_tall_variant(v)
+    us = t(own)
+    print(f"{nm:32s} {us:8.1f} us  {fl / us / 1e6:6.1f} TFLOP/s   max err vs torch {float((C - dv.t() @ feat).abs().max()):.3e}")
+L.sgs_gemm_tn_set_tall_variant(-1)
