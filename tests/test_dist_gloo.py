@@ -80,3 +80,30 @@ def test_shard_bounds_are_chunk_aligned_and_cover_everything():
             assert b[0] == 0 and b[-1] == E and len(b) == world + 1
             assert all(b[i] <= b[i + 1] for i in range(world))
             assert all(x % 2048 == 0 or x == E for x in b[:-1])   # interior boundaries on reduction-chunk boundaries (or empty tail shards)
+
+
+def test_lookahead_iteration_and_workspace_slots():
+    """Host logic of the prefix prefetch (stepgraph.py): the epoch loop reads the loader one batch ahead, and work recorded for a
+    second stream takes its scratch from its own arena."""
+    from sgs_gnn_amd import ops
+    from sgs_gnn_amd.training import _with_lookahead
+    assert list(_with_lookahead(iter([1, 2, 3]), True)) == [(1, 2), (2, 3), (3, None)]
+    assert list(_with_lookahead(iter([7]), True)) == [(7, None)]
+    assert list(_with_lookahead(iter([]), True)) == []
+    assert list(_with_lookahead([1, 2], False)) == [(1, None), (2, None)]
+    # a generator-backed loader is consumed exactly once, in order
+    seen = []
+
+    def gen():
+        for i in range(4):
+            seen.append(i)
+            yield i
+    pairs = list(_with_lookahead(gen(), True))
+    assert [p[0] for p in pairs] == [0, 1, 2, 3] and seen == [0, 1, 2, 3]
+    assert ops._ws_slot == 0
+    with ops.workspace_slot(1):
+        assert ops._ws_slot == 1
+        with ops.workspace_slot(2):
+            assert ops._ws_slot == 2
+        assert ops._ws_slot == 1
+    assert ops._ws_slot == 0
