@@ -144,6 +144,28 @@ def cpu_baseline(batch_cpu, steps=2):
                                       f"n={N_NODES}, E={E}, q={Q}, F={NFEAT}, H={HID}, fp32, torch {torch.__version__} CPU"}
 
 
+def pool_indices(sizes, rank, world, per_rank):
+    """Which partitions of the common stream rank `rank` holds, in step order.  Data-parallel steps end in a gradient all-reduce, so
+    a step lasts as long as its slowest rank: the stream is dealt out BY SIZE (sorted by edge count, rank r takes every world-th
+    one), so that the partitions the ranks process in the same step have adjacent sizes -- in particular all sampled or all
+    unsampled -- and the step order is then shuffled with a permutation common to all ranks."""
+    import random
+    order = sorted(range(len(sizes)), key=lambda i: (sizes[i], i))
+    mine = order[rank::world][:per_rank]
+    perm = random.Random(1000).sample(range(len(mine)), len(mine))
+    return [mine[i] for i in perm]
+
+
+def make_pool(S, rank, world, per_rank, device):
+    if world == 1:
+        return S.reddit_partition_stream(num_parts=per_rank, seed=1000, nfeat=NFEAT, ncls=NCLS, n=N_NODES, q=Q, device=device)
+    sizes = S.reddit_partition_sizes(per_rank * world, seed=1000, q=Q)
+    idx = pool_indices(sizes, rank, world, per_rank)
+    parts = S.reddit_partition_stream(num_parts=per_rank * world, seed=1000, nfeat=NFEAT, ncls=NCLS, n=N_NODES, q=Q, device=device,
+                                      only=set(idx))
+    return [parts[i] for i in idx]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,7 +202,7 @@ def main():
     args = make_args(device)
 
     # partition pool (per rank: its own shard of the stream), resident in HBM before timing
-    pool = S.reddit_partition_stream(num_parts=a.pool, seed=1000 + rank, nfeat=NFEAT, ncls=NCLS, n=N_NODES, q=Q, device=device)
+    pool = make_pool(S, rank, world, a.pool, device)
     warm = [pool[i % len(pool)] for i in range(a.warmup)]
     if a.hipgraph:
         args.sgs_hipgraph = True
@@ -251,7 +273,7 @@ def main():
             "config": {"workload": "Reddit-like METIS partition stream (S3): n=1013 F=602 C=41 H=256, E_b in [60k,500k] "
                                    "(52% above q), q=100000, hybrid pipeline, EdgeProbGCN scorer, conditional gate, reg1+reg2, "
                                    "dropout 0.3, Adam x2", "pool": a.pool, "partitions_above_q": sum(1 for b in timed if b.edge_index.shape[1] > Q),
-                       "parallelism": f"dp{world} (partition-sharded, 1 flat gradient all-reduce/step)" if world > 1 else "single",
+                       "parallelism": f"dp{world} (partition-sharded by size across ranks, 1 flat gradient all-reduce/step)" if world > 1 else "single",
                        "hipgraph_replay": bool(getattr(args, "sgs_hipgraph", False)),
                        "adam": "sgs_gnn_amd.FusedAdam (in-graph)" if a.fused_adam else "torch.optim.Adam (foreach, eager)"},
             "mean_loss": round(ret[0], 5), "conditional_updates": ret[2], "total_updates": ret[3],

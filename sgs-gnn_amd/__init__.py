@@ -10,4 +10,4 @@ from .training import train, train_hybrid, train_straight_through, train_two_pas
 from .evaluate import evaluate, ensemble_evaluate  # noqa: F401
 from .utils import calculate_f1, consistency_loss, fix_seeds  # noqa: F401
 from .optim import FusedAdam  # noqa: F401
-from .data import Batch, ResidentPartitions, degree_prior, synthetic_graph, reddit_partition_stream  # noqa: F401
+from .data import Batch, ResidentPartitions, degree_prior, synthetic_graph, reddit_partition_stream, reddit_partition_sizes  # noqa: F401

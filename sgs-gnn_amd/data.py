@@ -73,19 +73,26 @@ def synthetic_graph(n: int, n_edges_target: int, nfeat: int, ncls: int, seed: in
 
 def reddit_partition_stream(num_parts: int = 230, seed: int = 42, nfeat: int = 602, ncls: int = 41, n: int = 1013,
                             e_lo: int = 60_000, e_hi: int = 500_000, frac_above_q: float = 0.52, q: int = 100_000,
-                            device="cpu"):
+                            device="cpu", only=None):
     """S3 of SURVEY.md section 8d: a Reddit-like METIS partition stream -- `num_parts` batches of
     ~1013 nodes whose intra-partition edge counts mirror the reference run (119 of 230 partitions
-    exceed q = 100 000; logs/pipeline_hybrid.log:8)."""
+    exceed q = 100 000; logs/pipeline_hybrid.log:8).  `only` (a set of indices): build just those partitions, None elsewhere."""
+    sizes = reddit_partition_sizes(num_parts, seed, e_lo, e_hi, frac_above_q, q)
+    return [synthetic_graph(n, E, nfeat, ncls, seed * 1000 + i, device=device) if only is None or i in only else None
+            for i, E in enumerate(sizes)]
+
+
+def reddit_partition_sizes(num_parts: int = 230, seed: int = 42, e_lo: int = 60_000, e_hi: int = 500_000, frac_above_q: float = 0.52,
+                           q: int = 100_000):
+    """Edge counts of `reddit_partition_stream`'s partitions (same seed -> same list), without building them."""
     g = torch.Generator().manual_seed(seed)
-    out = []
+    sizes = []
     for i in range(num_parts):
         # deterministic interleave: every prefix of the stream has ~frac_above_q of its partitions above q
         above = int((i + 1) * frac_above_q) > int(i * frac_above_q)
         lo, hi = (int(q * 1.02), e_hi) if above else (e_lo, int(q * 0.98))
-        E = int(lo + (hi - lo) * float(torch.rand(1, generator=g)))
-        out.append(synthetic_graph(n, E, nfeat, ncls, seed * 1000 + i, device=device))
-    return out
+        sizes.append(int(lo + (hi - lo) * float(torch.rand(1, generator=g))))
+    return sizes
 
 
 class ResidentPartitions:

@@ -107,3 +107,25 @@ def test_lookahead_iteration_and_workspace_slots():
             assert ops._ws_slot == 2
         assert ops._ws_slot == 1
     assert ops._ws_slot == 0
+
+
+def test_bench_pool_is_dealt_out_by_size_across_ranks():
+    """bench.py --gpus N: the common partition stream is dealt out by edge count, so the partitions processed in the same
+    data-parallel step have adjacent sizes (a step lasts as long as its slowest rank); every partition is used exactly once."""
+    import bench as B
+    import sgs_gnn_amd as S
+    for world in (2, 4, 8):
+        sizes = S.reddit_partition_sizes(12 * world, seed=1000, q=B.Q)
+        idx = [B.pool_indices(sizes, r, world, 12) for r in range(world)]
+        assert sorted(i for l in idx for i in l) == list(range(12 * world))
+        mixed = sum(1 for k in range(12) if len({sizes[idx[r][k]] > B.Q for r in range(world)}) > 1)
+        assert mixed <= 1
+        for k in range(12):
+            col = [sizes[idx[r][k]] for r in range(world)]
+            assert max(col) <= 1.7 * min(col)
+        above = [sum(sizes[i] > B.Q for i in l) for l in idx]
+        assert max(above) - min(above) <= 1
+    # one rank: the stream itself (what the single-GPU bench line has always used)
+    assert S.reddit_partition_sizes(12, seed=1000, q=B.Q) == S.reddit_partition_sizes(24, seed=1000, q=B.Q)[:12]
+    parts = S.reddit_partition_stream(num_parts=6, seed=1000, nfeat=8, ncls=3, n=50, e_lo=100, e_hi=400, q=200, only={1, 4})
+    assert [p is not None for p in parts] == [False, True, False, False, True, False]
