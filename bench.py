@@ -206,6 +206,7 @@ def main():
     warm = [pool[i % len(pool)] for i in range(a.warmup)]
     if a.hipgraph:
         args.sgs_hipgraph = True
+        args.sgs_dp_global_gate = world > 1      # N > 1: one gate per step over the union of the ranks' batches (dist.py)
         warm = list(pool) * 2 + warm
     timed = [pool[i % len(pool)] for i in range(a.steps)]
     sampled = sum(Q for b in timed if b.edge_index.shape[1] > Q)
@@ -273,7 +274,7 @@ def main():
             "config": {"workload": "Reddit-like METIS partition stream (S3): n=1013 F=602 C=41 H=256, E_b in [60k,500k] "
                                    "(52% above q), q=100000, hybrid pipeline, EdgeProbGCN scorer, conditional gate, reg1+reg2, "
                                    "dropout 0.3, Adam x2", "pool": a.pool, "partitions_above_q": sum(1 for b in timed if b.edge_index.shape[1] > Q),
-                       "parallelism": f"dp{world} (partition-sharded by size across ranks, 1 flat gradient all-reduce/step)" if world > 1 else "single",
+                       "parallelism": f"dp{world} (partition-sharded by size across ranks, global gate, 1 flat gradient all-reduce/step)" if world > 1 else "single",
                        "hipgraph_replay": bool(getattr(args, "sgs_hipgraph", False)),
                        "adam": "sgs_gnn_amd.FusedAdam (in-graph)" if a.fused_adam else "torch.optim.Adam (foreach, eager)"},
             "mean_loss": round(ret[0], 5), "conditional_updates": ret[2], "total_updates": ret[3],

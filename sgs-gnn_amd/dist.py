@@ -10,6 +10,9 @@ instead of one per tensor, sized for xGMI's per-link bandwidth.
 Gate semantics under DP: each rank evaluates its own learned-vs-random gate on its own batch;
 the scorer's optimiser steps on every rank iff at least one rank's gate chose "learned"
 (ranks whose gate chose "random" contribute zero scorer gradients), so replicas stay identical.
+Opt-in `args.sgs_dp_global_gate` (graph mode with FusedAdam; what `bench.py --gpus N` sets): ONE gate per step over the union
+of the ranks' batches -- the four counts are summed over ranks (16 bytes) and micro-F1 is compared on the sums -- so all ranks
+take the same branch and no rank waits through another's learned backward.
 """
 from __future__ import annotations
 
@@ -52,6 +55,15 @@ class GradSync:
         """Graph mode: the gradients (and the flag word) were written into the bucket by a replayed backward graph; sum over
         ranks.  The division by the world size and the optimiser steps are replayed from their own graph afterwards."""
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+
+    def gate_sum(self, counts4: torch.Tensor) -> torch.Tensor:
+        """Global gate (args.sgs_dp_global_gate): the ranks' [#correct learned, #train, #correct random, #train] summed in place, so
+        that learned-vs-random is decided once for the union of the ranks' batches and every rank runs the SAME backward branch
+        (with per-rank gates a step waits for the one rank whose gate picked the ten times longer learned backward).  Ranks whose
+        partition is not sampled pass zeros."""
+        if is_parallel():
+            dist.all_reduce(counts4, op=dist.ReduceOp.SUM)
+        return counts4
 
     def any_learned(self, learned_local: torch.Tensor) -> torch.Tensor:
         """Device-side: sum over ranks of this rank's 0/1 gate outcome (enqueue BEFORE the gate read-back)."""

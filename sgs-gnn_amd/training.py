@@ -241,6 +241,7 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
             # N > 1 with FusedAdam: a replayed step all-reduces the gradient bucket and replays the optimiser graph inside
             # h.backward(); the "any rank learned" word travels in that bucket and is read on the device
             fused_dp = h is not None and graphs.dp and h.loss_on_device
+            global_gate = bool(getattr(args, "sgs_dp_global_gate", False))
             esync = sync if not fused_dp else None            # the eager collectives below are for every other case
             sampled = h.sampled if h is not None else batch.edge_index.shape[1] > q
             if sampled:
@@ -250,7 +251,12 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
                 update_edge_mlp = True
                 counts = None
                 any_learned = False
-                if args.conditional and h is not None and esync is None:
+                if args.conditional and fused_dp and global_gate:
+                    sync.gate_sum(h.cbuf[0:4])                                     # one gate for the union of the ranks' batches
+                    counts = h.cbuf.tolist()
+                    counts = [counts[0:2], counts[2:4]]
+                    update_edge_mlp = counts[0][0] > counts[1][0]                  # micro-F1 over the union: same denominator on both sides
+                elif args.conditional and h is not None and esync is None:
                     counts = h.gate_counts() + [0]                                 # replay: polled from pinned host memory
                     counts = [counts[0:2], counts[2:4]]
                     update_edge_mlp = counts[0][0] > counts[1][0]
@@ -297,6 +303,8 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
                                  random_out=None if st.random_out is None else st.random_out.detach(), counts=counts,
                                  update_edge_mlp=update_edge_mlp, loss=loss.detach())
             else:
+                if fused_dp and global_gate and args.conditional:
+                    sync.gate_sum(torch.zeros(4, dtype=torch.int32, device=batch.x.device))   # keep the gate collective in lock-step
                 if h is None:
                     out = model(batch, batch.edge_index)
                     loss = _ce(criterion, out, batch)

@@ -113,7 +113,7 @@ def test_sharded_draw_and_forward_are_rank_count_invariant():
             torch.testing.assert_close(pt["fwd"]["out"], base["out"], rtol=1e-4, atol=1e-5)
 
 
-def _dp_worker(rank, world, port, q_out, hipgraph=False):
+def _dp_worker(rank, world, port, q_out, hipgraph=False, global_gate=False):
     import sys
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -135,13 +135,37 @@ def _dp_worker(rank, world, port, q_out, hipgraph=False):
         batches = [S.synthetic_graph(300, e, 12, 5, seed=10 * rank + i, train_frac=0.5, device=DEV) for i, e in enumerate(sizes)]
         args = argparse.Namespace(device=DEV, mode="learned", pipeline="hybrid", conditional=True, sparse_edge_mlp=True, t_init=0.7,
                                   t_min=0.5, degree_bias_coef=0.3, reg1=True, reg2=True, regularizer1_coef=1.0,
-                                  consist_reg_coef=0.5, hybrid_checkpoint=False, sgs_hipgraph=hipgraph)
+                                  consist_reg_coef=0.5, hybrid_checkpoint=False, sgs_hipgraph=hipgraph, sgs_dp_global_gate=global_gate)
         with contextlib.redirect_stdout(io.StringIO()):
             for ep in range(4):
                 ret = S.train(args, ep, 4, m, opt_gnn, opt_edge, opt_all, torch.nn.CrossEntropyLoss(), batches, q=1000)
         q_out.put((rank, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, ret[2], ret[3]))
     finally:
         dist.destroy_process_group()
+
+
+def test_data_parallel_global_gate_keeps_replicas_identical():
+    """args.sgs_dp_global_gate (what bench.py --gpus N sets): one gate per step over the union of the ranks' batches -- the four
+    counts are summed over ranks, every rank takes the same branch; ranks whose partition is not sampled join the collective
+    with zeros (the test's ranks mix sampled and unsampled partitions in the same step).  Replicas stay bit-identical."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, True, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, sd, cond, tot = q.get(timeout=120)
+        got[rank] = (sd, cond, tot)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert got[0][2] == got[1][2] == 3
+    for k in got[0][0]:
+        a, b = torch.from_numpy(got[0][0][k]), torch.from_numpy(got[1][0][k])
+        assert torch.equal(a, b), k
+        assert bool(torch.isfinite(a).all())
 
 
 @pytest.mark.parametrize("hipgraph", [False, True])
