@@ -187,11 +187,19 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the SGS hot path has no CPU fallback")
+    # rehearsal on a one-GPU box (SGS_BENCH_REHEARSE=1): every rank on cuda:0 over gloo -- exercises the N > 1 code path
+    # (pool dealing, graph-mode data parallel, collectives), says nothing about speed
+    rehearse = os.environ.get("SGS_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device(device))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(device))
 
     import sgs_gnn_amd as S
     if a.score_variant >= 0:
