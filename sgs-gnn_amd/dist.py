@@ -25,7 +25,8 @@ def is_parallel() -> bool:
 
 
 def shard_batches(batches, rank: int, world: int):
-    """Partition-level sharding: rank r owns batches r, r + world, ..."""
+    """Partition-level sharding: rank r owns batches r, r + world, ...  Shards may differ in length by one (P % world != 0):
+    `train` agrees on the longest shard at the start of every epoch and the shorter ranks finish with null steps."""
     return [b for i, b in enumerate(batches) if i % world == rank]
 
 
@@ -50,6 +51,14 @@ class GradSync:
             self.flat = torch.zeros(self.numel + 1, dtype=torch.float32, device=device)
             self.views = [v.view_as(p) for v, p in zip(self.flat[:self.numel].split(self.sizes), self.params)]
             self.flag = self.flat[self.numel:self.numel + 1]
+
+    def max_steps(self, n_local: int, device) -> int:
+        """Largest per-rank step count of this epoch (one small all-reduce per epoch)."""
+        if not is_parallel():
+            return n_local
+        t = torch.tensor([n_local], dtype=torch.int64, device=device if dist.get_backend() != "gloo" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item())
 
     def all_reduce_bucket(self) -> None:
         """Graph mode: the gradients (and the flag word) were written into the bucket by a replayed backward graph; sum over

@@ -41,6 +41,7 @@ def _run(args, model, cluster_loader, device, q, mode, n_draws):
     with torch.no_grad():
         for batch in cluster_loader:
             batch = batch.to(device)
+            ops.new_memo_scope()
             edge_probs = None
             if mode == 'learned' and batch.edge_index.shape[1] > q:
                 edge_probs = model.edge_prob_mlp(batch.x, batch.edge_index).squeeze()         # encoder over the FULL batch graph

@@ -60,7 +60,9 @@ class GCNConv(nn.Module):
         GNNModel twice on the same batch.x with the same weights (learned and random forward,
         training_hybrid.py:88,93); the weight gradient is computed by hand in the layer's backward."""
         W = self.lin.weight
-        key = (x.data_ptr(), x._version, tuple(x.shape), W.data_ptr(), W._version)
+        # `ops.memo_scope()`: the trainers / evaluators open a new scope per batch, so a memo never outlives the step it was
+        # made in -- version counters alone are not enough (a replayed optimiser graph writes W without touching them)
+        key = (ops.memo_scope(), x.data_ptr(), x._version, tuple(x.shape), W.data_ptr(), W._version)
         c = getattr(self, "_lin_cache", None)
         if c is not None and c[0] == key and c[1]() is x:
             return c[2], key

@@ -86,6 +86,30 @@ def pin_workspaces(on: bool = True) -> None:
     _pin_workspaces = _pin_workspaces or bool(on)
 
 
+# ------------------------------------------------------------------ memo scope
+_memo_scope = 0
+
+
+def memo_scope() -> int:
+    """Identifier of the current memo scope: per-step memos (GCNConv's x W^T shared by the learned and the random forward of one
+    step) are keyed on it, so they can only be hit inside the step that made them."""
+    return _memo_scope
+
+
+def new_memo_scope() -> int:
+    """Open a new scope (called once per batch by train / evaluate): every memo made before is dead from here on."""
+    global _memo_scope
+    _memo_scope += 1
+    return _memo_scope
+
+
+def drop_memos(module) -> None:
+    """Forget every memoised x W^T held by `module`'s layers (after a capture: the memo would point into a graph's pool)."""
+    for mod in module.modules():
+        if getattr(mod, "_lin_cache", None) is not None:
+            mod._lin_cache = None
+
+
 # ------------------------------------------------------------------ randomness
 _rng_epoch = None       # keeps the registered device word alive
 

@@ -73,4 +73,7 @@ class FusedAdam(torch.optim.Optimizer):
                 _lib.check(L.sgs_adam_step(arr, len(part), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                            float(group["weight_decay"]), int(bool(group["maximize"])), tk.data_ptr(), stream),
                            "sgs_adam_step")
+                # the kernel wrote the parameters through raw pointers: tell autograd / version-keyed caches, as an in-place
+                # torch op would have
+                torch.autograd.graph.increment_version(part)
         return loss

@@ -68,8 +68,11 @@ class EdgeProbMLP(nn.Module):
             table = torch.cat([A[g[0]] * kx / (1 - p), A[g[1]] * ky / (1 - p)], dim=0)      # [2E',H] endpoint codes
             ar = torch.arange(Eg, device=A.device)
             pair = torch.stack([ar, ar + Eg])
+            # the scored object is the pseudo-graph `pair` over the 2E' table rows, not the batch graph: the trainer's active set
+            # (edge ids / CSR of the batch graph) does not apply to it, so the backward runs densely over `pair` with its own CSR
+            self.last_active = None
             prob = ops.edge_score(table, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, pair,
-                                  active=self.last_active, p=p, seed=ss, site=SITE_SCORE)
+                                  active=None, p=p, seed=ss, site=SITE_SCORE)
         return prob.unsqueeze(1)
 
 

@@ -185,6 +185,17 @@ class StepGraphs:
 
     def release(self):
         ops.set_rng_epoch_buffer(None)
+        ops.drop_memos(self.model)          # a memo made during a capture points into that graph's pool
+
+    def null_step(self):
+        """Data-parallel step without a batch (training._null_step): zero gradients and flag word into the bucket, the step's one
+        all-reduce, then the shared optimiser graph -- the same collectives and the same update as the ranks that had a batch."""
+        if self.g3 is None:
+            self._capture_g3()
+        self.sync._ensure(self.device)
+        self.sync.flat.zero_()
+        self.sync.all_reduce_bucket()
+        self.g3.replay()
 
     # ------------------------------------------------------------------ capture
     def _grads(self):
@@ -228,6 +239,7 @@ class StepGraphs:
         try:
             return self._capture_segments(batch, key)
         finally:
+            ops.drop_memos(self.model)      # memos made inside the capture hold graph-pool memory a later replay overwrites
             if was_enabled:
                 gc.enable()
 
@@ -246,9 +258,8 @@ class StepGraphs:
         self._clear_grads()
         torch.cuda.synchronize()
         c.g1 = torch.cuda.CUDAGraph()
-        for mod in self.model.modules():               # no memoised x W^T from an eager step may leak into a capture
-            if hasattr(mod, "_lin_cache"):
-                mod._lin_cache = None
+        ops.drop_memos(self.model)                     # no memoised x W^T from an eager step may leak into a capture
+        ops.new_memo_scope()
         if self.dp and self.g3 is None:
             self._capture_g3()
         if not c.sampled:

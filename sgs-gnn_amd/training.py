@@ -154,16 +154,23 @@ def train(args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, opt
                   cluster_loader, q)
 
 
-def train_hybrid(*a, **k):
-    return _train("hybrid", *a[:9], k.get("q", a[9] if len(a) > 9 else 500))
+def train_hybrid(args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, optimizer, criterion, cluster_loader,
+                 q=500, alternate_frequency=1):
+    """training_hybrid.train (training_hybrid.py:7-8): same positional / keyword signature (`alternate_frequency` is dead there too)."""
+    return _train("hybrid", args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, optimizer, criterion, cluster_loader, q)
 
 
-def train_straight_through(*a, **k):
-    return _train("straight_through", *a[:9], k.get("q", a[9] if len(a) > 9 else 500))
+def train_straight_through(args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, optimizer, criterion, cluster_loader,
+                           q=500, alternate_frequency=1):
+    """training_straight_through.train (training_straight_through.py:7-8)."""
+    return _train("straight_through", args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, optimizer, criterion,
+                  cluster_loader, q)
 
 
-def train_two_pass(*a, **k):
-    return _train("two_pass", *a[:9], k.get("q", a[9] if len(a) > 9 else 500))
+def train_two_pass(args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, optimizer, criterion, cluster_loader,
+                   q=500, alternate_frequency=1):
+    """training_two_pass.train (training_two_pass.py:7-8)."""
+    return _train("two_pass", args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, optimizer, criterion, cluster_loader, q)
 
 
 def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, optimizer, criterion,
@@ -212,6 +219,38 @@ def _with_lookahead(loader, on: bool):
     yield cur, None
 
 
+def _null_step(args, mode, model, optimizer_gnn, optimizer_edge_prob, optimizer, sync, graphs, device):
+    """A data-parallel step on a rank that has no batch left: joins exactly the collectives a real step issues, contributes zero
+    gradients and applies the same averaged update as the other ranks, so replicas stay identical."""
+    if mode != 'learned':
+        for p in sync.params:
+            p.grad = None
+        sync.sync()
+        optimizer.step()
+        return
+    if graphs is not None and graphs.dp:                         # replayed steps: [gate sum] -> bucket all-reduce -> shared optimiser graph
+        if args.conditional and bool(getattr(args, "sgs_dp_global_gate", False)):
+            sync.gate_sum(torch.zeros(4, dtype=torch.int32, device=device))
+        graphs.null_step()
+        return
+    optimizer_edge_prob.zero_grad()
+    optimizer_gnn.zero_grad()
+    flag = sync.any_learned(torch.zeros(1, dtype=torch.int32, device=device))
+    some_learned = int(flag.item()) > 0
+    if not some_learned:
+        # nobody learned: exactly the GNN-only tensors carry gradients on the other ranks (random branch / unsampled step);
+        # zeros here, so that this rank's Adam moves them with the same averaged gradient
+        scorer = {id(p) for g in optimizer_edge_prob.param_groups for p in g["params"]}
+        for g in optimizer_gnn.param_groups:
+            for p in g["params"]:
+                if id(p) not in scorer:
+                    p.grad = torch.zeros_like(p)
+    sync.sync(all_random=not some_learned)
+    if some_learned:
+        optimizer_edge_prob.step()
+    optimizer_gnn.step()
+
+
 def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, optimizer, criterion,
                 cluster_loader, q, device, mode, use_checkpoint, noise, trace, sync, graphs):
     total_loss = None
@@ -221,9 +260,17 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
     h = None
     if graphs is not None:
         graphs.loss_sum.zero_()
-    for batch, batch_after in _with_lookahead(cluster_loader, graphs is not None and mode == 'learned'):
+    loader, n_null = cluster_loader, 0
+    if sync is not None:
+        # N > 1: every step ends in collectives, so all ranks must run the same number of steps.  Shards may differ in length
+        # (P % world != 0) and a rank may skip a batch without train nodes: agree on the maximum once per epoch and let the
+        # ranks that run out join the remaining steps' collectives with zero gradients (`_null_step`).
+        loader = [b for b in cluster_loader if _has_train_nodes(b)]
+        n_null = sync.max_steps(len(loader), torch.device(device)) - len(loader)
+    for batch, batch_after in _with_lookahead(loader, graphs is not None and mode == 'learned'):
         if not _has_train_nodes(batch):
             continue
+        ops.new_memo_scope()                    # per-step memos (x W^T shared by the learned and the random forward) die here
         total_update += 1
         optimizer_edge_prob.zero_grad()
         optimizer_gnn.zero_grad()
@@ -330,6 +377,8 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
                 out = model(batch, batch.edge_index)
             loss = _ce(criterion, out, batch)
             loss.backward()
+            if sync is not None:
+                sync.sync()
             optimizer.step()
 
         elif mode == 'edge':
@@ -340,6 +389,8 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
                 out = model(batch, batch.edge_index)
             loss = _ce(criterion, out, batch)
             loss.backward()
+            if sync is not None:
+                sync.sync()
             optimizer.step()
 
         elif mode == 'full':
@@ -347,6 +398,8 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
             out = model(batch, batch.edge_index)
             loss = _ce(criterion, out, batch)
             loss.backward()
+            if sync is not None:
+                sync.sync()
             optimizer.step()
 
         else:
@@ -356,6 +409,9 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
             pass                            # replayed graphs add their loss to graphs.loss_sum on the device
         else:
             total_loss = loss.detach().clone() if total_loss is None else total_loss + loss.detach()
+
+    for _ in range(n_null):
+        _null_step(args, mode, model, optimizer_gnn, optimizer_edge_prob, optimizer, sync, graphs, torch.device(device))
 
     loss_total = float(total_loss) if total_loss is not None else 0.0
     if graphs is not None:

@@ -279,6 +279,75 @@ def gen_pipeline(rec, name, pipeline, scorer, drop, conditional, nsteps, seed):
           f"cond={[s['ret_cond'] for s in steps]}")
 
 
+def gen_pipeline_fullsize(rec, name, pipeline, salt, n=1013, nfeat=602, ncls=41, hid=256, e_target=210_000, q=100_000, nsteps=1,
+                          conditional=True):
+    """One Reddit-partition-sized step of the REFERENCE's trainer (S3 shapes: n=1013, F=602, H=256, C=41, q=100 000), so that the
+    kernels the HIP path auto-selects at production size (bf16x6 scorer forward / backward core, dv.W1a row GEMM, tall-K weight
+    gradient GEMM) are compared with the reference itself.  Inputs and the initial state are rebuilt from integer hashes
+    (tests/golden/portable.py) on the test side; stored here: the Exp(1) noise both multinomials consumed, and the reference's
+    outputs (scores of all E edges, packed masks, logits, loss, gate, all gradients)."""
+    import model as ref_model
+    import training as ref_training
+    import portable as PT
+    part = PT.make_partition(n, nfeat, ncls, e_target, salt)
+    ei = part["edge_index"]
+    E = ei.shape[1]
+    prob = PT.degree_prior(ei, n)
+    b = Batch(x=part["x"], edge_index=ei, y=part["y"], train_mask=part["train_mask"], val_mask=~part["train_mask"],
+              test_mask=~part["train_mask"], prob=prob)
+    args = ref_args(pipeline, "GCN", 0.0, conditional)
+    torch.manual_seed(salt)
+    m = ref_model.GNNModel(nfeat, hid, ncls, dropout_prob=0.0, edge_mlp_type="GCN")
+    sd0 = PT.init_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, salt + 5000)
+    m.load_state_dict(sd0)
+    opt_gnn = torch.optim.Adam([p for n_, p in m.named_parameters() if "gcn" in n_], lr=args.lr)
+    opt_edge = torch.optim.Adam([p for n_, p in m.named_parameters() if "edge_prob_mlp" in n_], lr=args.lr)
+    opt_all = torch.optim.Adam(m.parameters(), lr=args.lr, weight_decay=5e-4)
+    crit = nn.CrossEntropyLoss()
+    cap = {}
+    h1 = m.edge_prob_mlp.register_forward_hook(lambda mod, i, o: cap.setdefault("scorer_out", []).append(o.detach().clone()))
+    h2 = m.register_forward_hook(lambda mod, i, o: cap.setdefault("gnn_out", []).append(
+        (i[1].clone(), None if len(i) < 3 or i[2] is None else i[2].detach().clone(), o.detach().clone())))
+    tmod = {"hybrid": "training_hybrid", "straight_through": "training_straight_through", "two_pass": "training_two_pass"}[pipeline]
+    tm = sys.modules[tmod]
+    real_sampler = tm.gumbel_softmax_sampling
+
+    def sampler_spy(*a, **k):
+        mask, w = real_sampler(*a, **k)
+        cap.setdefault("sampler", []).append((mask.clone(), w.detach().clone()))
+        return mask, w
+    tm.gumbel_softmax_sampling = sampler_spy
+    steps = []
+    try:
+        for epoch in range(nsteps):
+            rec.clear()
+            cap.clear()
+            ret = ref_training.train(args, epoch, 10, m, opt_gnn, opt_edge, opt_all, crit, [b], q=q, alternate_frequency=0)
+            st = dict(ret_loss=float(ret[0]), ret_temperature=float(ret[1]), ret_cond=int(ret[2]), ret_total=int(ret[3]))
+            st["noise"] = [n_ for (_, _, n_, _) in rec.noise]
+            rmask = torch.zeros(E, dtype=torch.bool)
+            if conditional:
+                rmask[rec.noise[0][3]] = True
+            st["prior_mask_packed"] = PT.pack_mask(rmask)
+            st["scorer_out"] = cap["scorer_out"][0].squeeze().clone()
+            st["mask_packed"] = PT.pack_mask(cap["sampler"][0][0])
+            st["gnn_out"] = [g[2] for g in cap.get("gnn_out", [])]
+            st["w_sampled"] = cap["gnn_out"][0][1]
+            st["correct"] = [int((g[2].argmax(1) == b.y)[b.train_mask].sum()) for g in cap.get("gnn_out", [])]    # the gate's F1 numerators
+            st["grads"] = {k: (v.grad.detach().clone() if v.grad is not None else torch.zeros(0)) for k, v in m.named_parameters()}
+            steps.append(st)
+    finally:
+        tm.gumbel_softmax_sampling = real_sampler
+        h1.remove()
+        h2.remove()
+    fx = dict(name=name, pipeline=pipeline, scorer="GCN", drop=0.0, conditional=conditional, q=q, salt=salt, n=n, nfeat=nfeat, ncls=ncls,
+              hid=hid, e_target=e_target, E=E, x_checksum=float(part["x"].double().sum()), ei_checksum=int(ei.sum()),
+              state0_checksum=float(sum(v.double().abs().sum() for v in sd0.values())), prob_checksum=float(prob.double().sum()),
+              steps=steps)
+    torch.save(fx, os.path.join(HERE, f"pipeline_{name}.pt"))
+    print(f"pipeline_{name}.pt: E={E} q={q} steps={nsteps} loss0={steps[0]['ret_loss']:.6f} cond={[s_['ret_cond'] for s_ in steps]}")
+
+
 def main():
     install_pyg_stub()
     sys.path.insert(0, REF)
@@ -293,8 +362,11 @@ def main():
             ("hybrid_mlp", "hybrid", "MLP", 0.0, False, 2, 104),
             ("hybrid_gcn_drop", "hybrid", "GCN", 0.3, True, 2, 105),
             ("twopass_mlp", "two_pass", "MLP", 0.0, False, 2, 106),
+            ("hybrid_mlp_drop", "hybrid", "MLP", 0.3, False, 2, 107),
         ]:
             gen_pipeline(rec, name, pipeline, scorer, drop, cond, nsteps, seed)
+        sys.path.insert(0, HERE)
+        gen_pipeline_fullsize(rec, "hybrid_gcn_s3size", "hybrid", salt=33)   # salt chosen so that the gate takes the learned branch
     finally:
         rec.uninstall()
 

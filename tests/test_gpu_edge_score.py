@@ -80,6 +80,48 @@ def test_active_subset_backward_equals_dense_with_masked_gradient(ops):
         assert _rel(a, b) < 1e-5
 
 
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_production_size_forward_and_active_backward_vs_fp64_oracle(ops, p):
+    """ops.edge_score forward + backward at the sizes where the library auto-selects its production kernels (E >= 65 536 and
+    H % 128 == 0: bf16x6 forward; >= 65 536 active rows: bf16x6 backward core, sgs_edge_score_bwd_dfeat row GEMM, tall-K bf16x6
+    weight-gradient GEMM with the bias gradient as by-product, paired endpoint reduction) against the fp64 oracle."""
+    import sgs_gnn_amd as S
+    L = S._lib.lib()
+    L.sgs_edge_score_set_variant(-1)
+    L.sgs_edge_score_set_bwd_variant(-1)
+    L.sgs_gemm_tn_set_tall_variant(-1)
+    N, H, E, q = 1013, 256, 150_001, 70_003
+    codes, ei, W1, b1, W2, b2, g = _case(N, H, E, 2024)
+    seed, site = 777, 2
+    eid = torch.sort(torch.randperm(E, generator=g)[:q]).values
+    gq = torch.randn(q, generator=g)
+    keep = ops.dropout_keep(seed, site, E, H, p, DEV).cpu() if p > 0 else None
+
+    # fp64 oracle: forward over all E edges (chunked: [E,2H] in fp64 is 0.6 GB), backward through the q active rows only
+    leaves = [t.clone().double().requires_grad_(True) for t in (codes, W1, b1, W2, b2)]
+    co, W1o, b1o, W2o, b2o = leaves
+    with torch.no_grad():
+        po_all = torch.cat([O.edge_score(co[ei[0, a:a + 32768]], co[ei[1, a:a + 32768]], W1o, b1o, W2o, b2o, p,
+                                         None if keep is None else keep[a:a + 32768]).squeeze(1) for a in range(0, E, 32768)])
+    sub = ei[:, eid]
+    po = O.edge_score(co[sub[0]], co[sub[1]], W1o, b1o, W2o, b2o, p, None if keep is None else keep[eid]).squeeze(1)
+    po.backward(gq.double())
+
+    dl = [t.clone().to(DEV).requires_grad_(True) for t in (codes, W1, b1, W2, b2)]
+    act = ops.ActiveSet()
+    pd = ops.edge_score(dl[0], dl[1], dl[2], dl[3], dl[4], ei.to(DEV), active=act, p=p, seed=seed, site=site)
+    assert float((pd.detach().cpu().double() - po_all).abs().max()) < 2e-6
+    act.set(eid.to(DEV), ops.Graph(sub.to(DEV), N))
+    gp = torch.zeros(E)
+    gp[eid] = gq
+    pd.backward(gp.to(DEV))
+    for name, a, b in zip(["dcodes", "dW1", "db1", "dW2", "db2"], dl, leaves):
+        if name == "db2":
+            assert abs(float(a.grad) - float(b.grad)) < 2e-6 * float(gq.abs().sum()) / 4, name
+        else:
+            assert _rel(a.grad, b.grad) < 2e-5, (name, _rel(a.grad, b.grad))
+
+
 def test_scorer_tail_and_probability_range(ops):
     N, H, E = 1013, 256, 100001          # E not a multiple of the 128-edge tile
     codes, ei, W1, b1, W2, b2, _ = _case(N, H, E, 3)

@@ -96,3 +96,56 @@ def test_fused_adam_device_gate():
     for a, b in zip(pa, pb):
         torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-7)
     assert float(ob.state[pb[0]]["step"]) == 3.0 and float(ob.state[pb[1]]["step"]) == 6.0
+
+
+def _single_batch_run(S, Adam, steps, hipgraph=False, evaluate_after=False):
+    """`cluster_loader = [data]` (main.py:67: graphs below the METIS threshold): ONE resident batch, visited every step."""
+    import argparse
+    import contextlib
+    import io
+    b = S.synthetic_graph(300, 9000, 12, 5, seed=3, train_frac=0.5, device=DEV)
+    torch.manual_seed(0)
+    m = S.GNNModel(12, 32, 5, dropout_prob=0.0, edge_mlp_type="GCN").to(DEV)
+    og = Adam([p for n, p in m.named_parameters() if "gcn" in n], lr=1e-2)
+    oe = Adam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-2)
+    oa = torch.optim.Adam(m.parameters(), lr=1e-2)
+    args = argparse.Namespace(device=DEV, mode="learned", pipeline="hybrid", conditional=True, sparse_edge_mlp=True, t_init=0.7, t_min=0.5,
+                              degree_bias_coef=0.3, reg1=True, reg2=True, regularizer1_coef=1.0, consist_reg_coef=0.5,
+                              hybrid_checkpoint=False, sgs_hipgraph=hipgraph, num_samples_eval=2)
+    S.fix_seeds(7)
+    with contextlib.redirect_stdout(io.StringIO()):
+        for ep in range(steps):
+            S.train(args, ep, steps, m, og, oe, oa, torch.nn.CrossEntropyLoss(), [b], q=2000)
+    ev = None
+    if evaluate_after:
+        S.fix_seeds(99)
+        ev = S.ensemble_evaluate(args, m, [b], DEV, q=2000, mode="learned")
+    return m, b, args, ev
+
+
+def test_fused_adam_on_one_resident_batch_is_not_served_stale_memos():
+    """GCNConv memoises x W^T within a step, keyed on tensor identity + version; FusedAdam writes W through raw pointers.  With one
+    resident batch (same x every step) a memo that survived the optimiser step would make every forward after the first ignore the
+    update.  Three eager steps with FusedAdam must track torch.optim.Adam (same noise streams, dropout 0)."""
+    import sgs_gnn_amd as S
+    ma, _, _, _ = _single_batch_run(S, torch.optim.Adam, 3)
+    mb, _, _, _ = _single_batch_run(S, S.FusedAdam, 3)
+    for (k, a), (_, b) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        torch.testing.assert_close(b, a, rtol=1e-4, atol=2e-6, msg=lambda s: f"{k}: {s}")
+    # and the parameters did move on every step: three steps of lr = 1e-2 differ from one
+    m1, _, _, _ = _single_batch_run(S, S.FusedAdam, 1)
+    assert float((m1.gcn1.lin.weight - mb.gcn1.lin.weight).abs().max()) > 5e-3
+
+
+def test_evaluate_after_a_replayed_epoch_sees_the_current_weights():
+    """After HIP-graph training (the optimiser steps run inside replayed graphs: no version counter moves), evaluate() on the same
+    resident batch must use the CURRENT weights: compare with evaluating a fresh model that was loaded with the same state_dict."""
+    import sgs_gnn_amd as S
+    m, b, args, ev = _single_batch_run(S, S.FusedAdam, 5, hipgraph=True, evaluate_after=True)
+    torch.manual_seed(1)
+    fresh = S.GNNModel(12, 32, 5, dropout_prob=0.0, edge_mlp_type="GCN").to(DEV)
+    fresh.load_state_dict(m.state_dict())
+    S.fix_seeds(99)
+    b2 = S.Batch(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.__dict__.items() if not k.startswith("_sgs")})
+    ev2 = S.ensemble_evaluate(args, fresh, [b2], DEV, q=2000, mode="learned")
+    assert ev == ev2

@@ -81,6 +81,95 @@ def test_train_replays_reference_fixture(name):
                                        msg=lambda s: f"step {epoch} param {k}: {s}")
 
 
+def test_train_replays_reference_fixture_at_partition_size():
+    """Config 3 at production size against the REFERENCE's own step (tests/golden/pipeline_hybrid_gcn_s3size.pt: n=1013, F=602,
+    H=256, C=41, E=210 000, q=100 000, GCN scorer, conditional gate, learned branch taken): eager train() here auto-selects the
+    bf16x6 scorer forward (E >= 65 536, H % 128 == 0), the bf16x6 backward core, the dv.W1a row GEMM and the tall-K bf16x6 weight
+    gradient GEMM (>= 65 536 active rows), so those kernels are compared with the reference, not only with the oracle."""
+    from conftest import load_golden_fullsize
+    import sgs_gnn_amd as S
+    fx = load_golden_fullsize("pipeline_hybrid_gcn_s3size.pt")
+    st = fx["steps"][0]
+    m = S.GNNModel(fx["nfeat"], fx["hid"], fx["ncls"], dropout_prob=0.0, edge_mlp_type="GCN")
+    m.load_state_dict(fx["state0"])
+    m = m.to(DEV)
+    opt_gnn = torch.optim.Adam([p for n, p in m.named_parameters() if "gcn" in n], lr=1e-3)
+    opt_edge = torch.optim.Adam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-3)
+    opt_all = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4)
+    b = S.Batch(x=fx["x"], edge_index=fx["edge_index"], y=fx["y"], train_mask=fx["train_mask"], prob=fx["prob"]).to(DEV)
+    args = _args(fx)
+    args._sgs_noise = {"prior": st["noise"][0].to(DEV), "sample": st["noise"][1].to(DEV)}
+    args._sgs_trace = tr = {}
+    L = S._lib.lib()
+    L.sgs_edge_score_set_variant(-1)
+    L.sgs_edge_score_set_bwd_variant(-1)
+    ret = S.train(args, 0, 10, m, opt_gnn, opt_edge, opt_all, nn.CrossEntropyLoss(), [b], q=fx["q"], alternate_frequency=0)
+    # draws: bit-exact edge sets (prior draw: torch's CPU softmax vs the device's expf differ by ulps in the keys; an edge set that
+    # differs would show here first)
+    assert torch.equal(tr["rsei"].cpu(), fx["edge_index"][:, st["prior_mask"]]), "prior draw differs from the reference's"
+    torch.testing.assert_close(tr["edge_probs_full"].cpu(), st["scorer_out"], rtol=0, atol=2e-6)
+    assert torch.equal(tr["sample"].mask.cpu(), st["mask"])
+    torch.testing.assert_close(tr["w"].cpu(), st["w_sampled"], rtol=0, atol=2e-6)
+    torch.testing.assert_close(tr["learned_out"].cpu(), st["gnn_out"][0], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(tr["random_out"].cpu(), st["gnn_out"][1], rtol=1e-4, atol=1e-4)
+    assert tr["counts"][0][0] == st["correct"][0] and tr["counts"][1][0] == st["correct"][1]
+    assert int(tr["update_edge_mlp"]) == st["ret_cond"] == 1
+    assert abs(ret[0] - st["ret_loss"]) < 1e-4
+    for k, v in m.named_parameters():
+        g = st["grads"][k]
+        # relative to the tensor's largest entry: at q = 100 000 summands the reference's own fp32 accumulation order shows at 1e-3
+        tol = 2e-3 * float(g.abs().max())
+        torch.testing.assert_close(v.grad.cpu(), g, rtol=2e-3, atol=tol, msg=lambda s_: f"grad {k}: {s_}")
+    # parameters after the optimiser steps: torch.optim.Adam's rule (both optimisers, edge_prob_mlp.gcn* updated twice) applied to
+    # the gradients compared above.  (The first Adam step moves every entry by ~lr * sign(g), so it is checked against the rule on
+    # the step's own gradients, not against the reference's parameters: an entry whose gradient is ~0 may legitimately step the other way.)
+    grads = {k: v.grad.cpu() for k, v in m.named_parameters()}
+    P = {k: v.clone() for k, v in fx["state0"].items()}
+    se, sg = {}, {}
+    O.adam_step({k: v for k, v in P.items() if "edge_prob_mlp" in k}, grads, se)
+    O.adam_step({k: v for k, v in P.items() if "gcn" in k}, grads, sg)
+    for k, v in m.state_dict().items():
+        torch.testing.assert_close(v.cpu(), P[k], rtol=1e-5, atol=2e-6, msg=lambda s_: f"param {k}: {s_}")
+
+
+def test_hybrid_mlp_scorer_with_dropout_matches_oracle():
+    """hybrid + --edge_mlp_type MLP + conditional False + dropout > 0 (the reference's only working training configuration of
+    EdgeProbMLP): the per-(edge, endpoint) dropout of model.py:21-25 keeps the scorer on its endpoint-table
+    path, whose backward must run over that table's own pseudo-graph.  Inputs / initial state: the reference fixture
+    pipeline_hybrid_mlp_drop.pt (which pins the oracle's EdgeProbMLP-with-dropout in tests/test_oracle_golden.py); the dropout
+    masks are the product's counter-based ones, exported to the oracle."""
+    import sgs_gnn_amd as S
+    M = S.model
+    fx = load_golden("pipeline_hybrid_mlp_drop.pt")
+    S_, m, opt_gnn, opt_edge, opt_all, b = _setup(fx)
+    args = _args(fx)
+    p, H, N, E = fx["drop"], 16, fx["x"].shape[0], fx["edge_index"].shape[1]
+    st = fx["steps"][0]
+    M.set_dropout_seed(11)
+    seeds = [M._DropoutClock.next_seed() for _ in range(4)]          # EdgeProbMLP: x, y, hidden; then GNNModel's hidden layer
+    M.set_dropout_seed(11)
+    keep = lambda sd, site, rows: S.ops.dropout_keep(sd, site, rows, H, p, DEV).cpu()      # noqa: E731
+    nz = O.StepNoise(sample_noise=st["noise"][0])
+    nz.masks_pass1 = O.Masks(mlp_x=keep(seeds[0], M.SITE_MLP_X, E), mlp_y=keep(seeds[1], M.SITE_MLP_Y, E),
+                             score_hidden=keep(seeds[2], M.SITE_SCORE, E))
+    nz.gnn_keep_learned = keep(seeds[3], M.SITE_GNN, N)
+    P = {k: v.clone().double().requires_grad_(True) for k, v in fx["state0"].items()}
+    cfg = O.StepConfig(pipeline="hybrid", scorer="MLP", q=fx["q"], conditional=False, drop_rate=p)
+    R = O.learned_step_forward(P, dict(x=fx["x"].double(), edge_index=fx["edge_index"], y=fx["y"], train_mask=fx["train_mask"],
+                                       prob=fx["prob"]), cfg, nz)
+    R["loss"].backward()
+
+    args._sgs_noise = {"sample": st["noise"][0].to(DEV)}
+    args._sgs_trace = tr = {}
+    ret = S.train(args, 0, 10, m, opt_gnn, opt_edge, opt_all, nn.CrossEntropyLoss(), [b], q=fx["q"], alternate_frequency=0)
+    torch.testing.assert_close(tr["edge_probs_full"].cpu().double(), R["edge_probs_full"].detach(), rtol=0, atol=2e-6)
+    assert torch.equal(tr["sample"].mask.cpu(), R["mask"])
+    torch.testing.assert_close(tr["learned_out"].cpu().double(), R["learned_out"].detach(), rtol=1e-4, atol=1e-4)
+    assert abs(ret[0] - float(R["loss"])) < 1e-4
+    for k, v in m.named_parameters():
+        torch.testing.assert_close(v.grad.cpu().double(), P[k].grad, rtol=2e-3, atol=2e-6, msg=lambda s_: f"grad {k}: {s_}")
+
+
 def test_losses_against_torch():
     import sgs_gnn_amd as S
     g = torch.Generator().manual_seed(0)

@@ -113,7 +113,7 @@ def test_sharded_draw_and_forward_are_rank_count_invariant():
             torch.testing.assert_close(pt["fwd"]["out"], base["out"], rtol=1e-4, atol=1e-5)
 
 
-def _dp_worker(rank, world, port, q_out, hipgraph=False, global_gate=False):
+def _dp_worker(rank, world, port, q_out, hipgraph=False, global_gate=False, uneven=False):
     import sys
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -132,7 +132,11 @@ def _dp_worker(rank, world, port, q_out, hipgraph=False, global_gate=False):
         opt_all = torch.optim.Adam(m.parameters(), lr=1e-2)
         # rank-specific partitions, one of them too small to be sampled (E <= q): exercises every sync branch
         sizes = [6000, 900, 5000] if rank == 0 else [5500, 7000, 800]
+        if uneven and rank == 0:
+            sizes = sizes + [6500]                                # 4 batches against 3: P % world != 0 (dist.shard_batches)
         batches = [S.synthetic_graph(300, e, 12, 5, seed=10 * rank + i, train_frac=0.5, device=DEV) for i, e in enumerate(sizes)]
+        if uneven and rank == 1:
+            batches[1].train_mask = torch.zeros_like(batches[1].train_mask)     # a batch the trainer skips on this rank only
         args = argparse.Namespace(device=DEV, mode="learned", pipeline="hybrid", conditional=True, sparse_edge_mlp=True, t_init=0.7,
                                   t_min=0.5, degree_bias_coef=0.3, reg1=True, reg2=True, regularizer1_coef=1.0,
                                   consist_reg_coef=0.5, hybrid_checkpoint=False, sgs_hipgraph=hipgraph, sgs_dp_global_gate=global_gate)
@@ -162,6 +166,31 @@ def test_data_parallel_global_gate_keeps_replicas_identical():
         p.join(120)
         assert p.exitcode == 0
     assert got[0][2] == got[1][2] == 3
+    for k in got[0][0]:
+        a, b = torch.from_numpy(got[0][0][k]), torch.from_numpy(got[1][0][k])
+        assert torch.equal(a, b), k
+        assert bool(torch.isfinite(a).all())
+
+
+@pytest.mark.parametrize("hipgraph", [False])
+def test_data_parallel_uneven_shards_finish_with_null_steps(hipgraph):
+    """Ranks with different step counts (4 usable batches on rank 0; 3 on rank 1, one of them without train nodes -> 2 steps): the
+    epoch agrees on the longest shard and the short rank joins the remaining steps' collectives with zero gradients
+    (training._null_step) -- no hang, replicas bit-identical."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, hipgraph, False, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, sd, cond, tot = q.get(timeout=300)
+        got[rank] = (sd, cond, tot)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert got[0][2] == 4 and got[1][2] == 2
     for k in got[0][0]:
         a, b = torch.from_numpy(got[0][0][k]), torch.from_numpy(got[1][0][k])
         assert torch.equal(a, b), k

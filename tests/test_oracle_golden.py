@@ -7,7 +7,7 @@ import torch.nn.functional as F
 from conftest import load_golden
 from oracle import sgs_oracle as O
 
-PIPE = ["hybrid_gcn", "st_gcn", "twopass_gcn", "hybrid_mlp", "hybrid_gcn_drop", "twopass_mlp"]
+PIPE = ["hybrid_gcn", "st_gcn", "twopass_gcn", "hybrid_mlp", "hybrid_gcn_drop", "twopass_mlp", "hybrid_mlp_drop"]
 
 
 def test_multinomial_is_exponential_race():
@@ -76,9 +76,13 @@ def _replay(fx, dtype=torch.float32):
         nz.sample_noise = noise.pop(0)
         keeps = list(st["drop_keep"])
         if fx["drop"] > 0:
-            assert fx["scorer"] == "GCN" and fx["pipeline"] == "hybrid"
-            nz.masks_pass1 = O.Masks(enc_hidden=keeps[0], score_hidden=keeps[1])
-            nz.gnn_keep_learned, nz.gnn_keep_random = keeps[2], keeps[3]
+            assert fx["pipeline"] == "hybrid"
+            if fx["scorer"] == "GCN":
+                nz.masks_pass1 = O.Masks(enc_hidden=keeps[0], score_hidden=keeps[1])
+                nz.gnn_keep_learned, nz.gnn_keep_random = keeps[2], keeps[3]
+            else:               # EdgeProbMLP (model.py:21-25, 32): x, y endpoint dropouts, hidden dropout; then the GNN's (conditional False)
+                nz.masks_pass1 = O.Masks(mlp_x=keeps[0], mlp_y=keeps[1], score_hidden=keeps[2])
+                nz.gnn_keep_learned = keeps[3]
         R = O.learned_step_forward(P, batch, cfg, nz)
         for p_ in P.values():
             p_.grad = None
@@ -117,6 +121,29 @@ def test_pipeline_replay_matches_reference(name):
     # after the last yield the generator applied the optimiser steps for the last fixture step too
     for k, v in fx["steps"][-1]["state_after"].items():
         torch.testing.assert_close(P[k].detach(), v, rtol=1e-5, atol=2e-6, msg=lambda m: f"{k}: {m}")
+
+
+def test_fullsize_fixture_replay_matches_reference():
+    """The oracle at Reddit-partition size (n=1013, F=602, H=256, C=41, E=210 000, q=100 000) against the reference's own step
+    (tests/golden/pipeline_hybrid_gcn_s3size.pt; inputs rebuilt from integer hashes, see conftest.load_golden_fullsize)."""
+    from conftest import load_golden_fullsize
+    fx = load_golden_fullsize("pipeline_hybrid_gcn_s3size.pt")
+    st = fx["steps"][0]
+    P = {k: v.clone().requires_grad_(True) for k, v in fx["state0"].items()}
+    cfg = O.StepConfig(pipeline="hybrid", scorer="GCN", q=fx["q"], conditional=True, drop_rate=0.0)
+    batch = dict(x=fx["x"], edge_index=fx["edge_index"], y=fx["y"], train_mask=fx["train_mask"], prob=fx["prob"])
+    nz = O.StepNoise(prior_noise=st["noise"][0], sample_noise=st["noise"][1])
+    R = O.learned_step_forward(P, batch, cfg, nz)
+    R["loss"].backward()
+    assert torch.equal(R["mask"], st["mask"])
+    torch.testing.assert_close(R["edge_probs_full"].detach(), st["scorer_out"], rtol=0, atol=1e-6)
+    torch.testing.assert_close(R["w"].detach(), st["w_sampled"], rtol=0, atol=1e-6)
+    torch.testing.assert_close(R["learned_out"].detach(), st["gnn_out"][0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(R["random_out"].detach(), st["gnn_out"][1], rtol=1e-5, atol=1e-5)
+    assert int(R["update_edge_mlp"]) == st["ret_cond"] == 1
+    assert abs(float(R["loss"].detach()) - st["ret_loss"]) < 1e-5
+    for k, g in st["grads"].items():
+        torch.testing.assert_close(P[k].grad, g, rtol=1e-3, atol=1e-6, msg=lambda m: f"{k}: {m}")
 
 
 def test_gcn_conv_against_dense_fp64_formula():
