@@ -74,6 +74,8 @@ class FusedAdam(torch.optim.Optimizer):
                                            float(group["weight_decay"]), int(bool(group["maximize"])), tk.data_ptr(), stream),
                            "sgs_adam_step")
                 # the kernel wrote the parameters through raw pointers: tell autograd / version-keyed caches, as an in-place
-                # torch op would have
-                torch.autograd.graph.increment_version(part)
+                # torch op would have.  Not while a HIP graph is being captured: nothing executes then, and the capture goes on to
+                # record the OTHER backward branch through the same saved tensors (only one of the two is replayed per step).
+                if not torch.cuda.is_current_stream_capturing():
+                    torch.autograd.graph.increment_version(part)
         return loss

@@ -134,7 +134,7 @@ def test_fused_adam_on_one_resident_batch_is_not_served_stale_memos():
         torch.testing.assert_close(b, a, rtol=1e-4, atol=2e-6, msg=lambda s: f"{k}: {s}")
     # and the parameters did move on every step: three steps of lr = 1e-2 differ from one
     m1, _, _, _ = _single_batch_run(S, S.FusedAdam, 1)
-    assert float((m1.gcn1.lin.weight - mb.gcn1.lin.weight).abs().max()) > 5e-3
+    assert float((m1.gcn1.lin.weight - mb.gcn1.lin.weight).detach().abs().max()) > 5e-3
 
 
 def test_evaluate_after_a_replayed_epoch_sees_the_current_weights():
