@@ -61,6 +61,27 @@ int sgs_dropout_keep(uint64_t seed, uint32_t site, int64_t rows, int64_t cols, f
                      sgs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * One captured step for partitions of ANY size (HIP-graph replay of training_hybrid.py:29-187's loop body without one capture
+ * per partition).  Sizes and pointers are launch arguments, frozen at capture; two entry points lift that:
+ *   sgs_dyn_edges_set : while a device word is registered, the entry points whose grids run over the CANDIDATE edges of a partition
+ *                       (sgs_sample_topq, sgs_edge_score_fwd, the dense part of sgs_st_weights_bwd, sgs_gather_by_eid /
+ *                       sgs_scatter_by_eid) use n = min(their size argument, *word) rows and treat the argument as the CAPACITY
+ *                       (grid size, row stride of `edge_index`, buffer and workspace sizes).  A drawn subgraph has q < E edges,
+ *                       so calls over it are unaffected.  Process-wide, read at launch (= capture) time; NULL = off.
+ *                       Everything downstream of the draw is sized by q and N, which a run fixes.
+ *   sgs_stage_segments: the batch hand-over of training_hybrid.py:42 (`batch.to(device)`) for resident partitions: ONE launch copies
+ *                       up to sgs_stage_max_segments() spans from a partition's resident arrays into the static buffers a
+ *                       captured step reads, pads each destination tail with a 32-bit word (zero rows for padded nodes, E for
+ *                       the row pointers past N, ...) and writes up to 4 dims words (the E that sgs_dyn_edges_set points at).
+ *                       desc_host [n_segments][5] int64, HOST memory, read during the call: {src, dst, src_bytes, dst_bytes >=
+ *                       src_bytes, pad word}; spans are whole 4-byte words.  HBM-bound: 16 B per lane, 16 KiB per workgroup.
+ * ---------------------------------------------------------------------------------- */
+int sgs_dyn_edges_set(const int64_t* n_edges_dev);
+int sgs_stage_max_segments(void);
+int sgs_stage_segments(const int64_t* desc_host, int64_t n_segments, int64_t* dims_dev, const int64_t* dims_host, int64_t n_dims,
+                       sgs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * K0 / K2 / K3: fused exponential-race top-q edge sampler + stable compaction.
  *
  * Replaces, in one call:
@@ -83,6 +104,11 @@ int sgs_dropout_keep(uint64_t seed, uint32_t site, int64_t rows, int64_t cols, f
  * compatible), sampled_eid[q] ascending edge ids, sampled_edge_index[2,q], sampled_p[q] =
  * p[sampled_eid], stats[4] = {Z (sum p or sum exp), max (prior mode), threshold key, #ties
  * taken at the threshold}.  keys_out[E] (optional) receives the fp32 keys (tests only).
+ * p == NULL (mode LEARNED, prior == NULL): uniform weights, i.e. a uniformly random q-subset of the edges -- the selection
+ * behind `random_edge_sampling` (sampling.py:159-163, torch.randperm(E)[:q]), emitted in original edge order.
+ *
+ * sgs_gather_columns: out[:, j] = edge_index[:, idx[j]] (sampling.py:163 with an explicit index vector, e.g. the first q
+ * entries of a given permutation); indices outside [0, E) give (-1, -1).
  * ---------------------------------------------------------------------------------- */
 #define SGS_SAMPLE_LEARNED 0
 #define SGS_SAMPLE_PRIOR 1
@@ -93,6 +119,8 @@ int sgs_sample_topq(int mode, const float* p, const float* prior, double degree_
                     const int64_t* edge_index, uint8_t* mask, int64_t* sampled_eid,
                     int64_t* sampled_edge_index, float* sampled_p, float* stats, float* keys_out,
                     void* ws, size_t ws_bytes, sgs_stream_t stream);
+
+int sgs_gather_columns(const int64_t* edge_index, int64_t E, const int64_t* idx, int64_t q, int64_t* out, sgs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Phase API of the sampler for EDGE-SHARDED draws (config 5: one graph, edges split over R ranks in

@@ -49,6 +49,8 @@ struct ScoreArgs {
     const int64_t* dst;      // [E]
     const int64_t* active;   // [n] edge ids (backward) or nullptr = identity
     int64_t n;               // rows processed (E forward, n_active backward)
+    const int64_t* dyn_n;    // forward under sgs_dyn_edges_set: the live row count is read from this device word; `n` is then only the
+                             // capacity the grid was sized for (HIP-graph replay of one captured step over partitions of any size)
     int64_t row_offset;      // global id of local edge 0 (edge-sharded graphs): dropout rows are global edge ids
     int H;
     const float* WaT;        // [H][H] k-major
@@ -89,6 +91,11 @@ __global__ void __launch_bounds__(kT, 3) edge_score_kernel(ScoreArgs a) {
     const int eg = wave & 1, hh = wave >> 1;
     const int H = EXACT ? HP : a.H;
     const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kBM;
+    if (a.dyn_n) {
+        const int64_t live_n = *a.dyn_n;                          // never more than the capacity the launch was sized for
+        if (live_n < a.n) a.n = live_n;
+        if (row0 >= a.n) return;                                  // (uniform per workgroup)
+    }
 
     if (tid < kBM) {
         const int64_t r = row0 + tid;
@@ -339,6 +346,11 @@ __global__ void __launch_bounds__(kT, 3) edge_score_stream_kernel(ScoreArgs a, c
     const int eg = wave & 1, hh = wave >> 1;
     const int kh = lane >> 5, l31 = lane & 31;
     const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kBM;
+    if (a.dyn_n) {
+        const int64_t live_n = *a.dyn_n;
+        if (live_n < a.n) a.n = live_n;
+        if (row0 >= a.n) return;
+    }
     const int el = 32 * eg + l31;
     const int64_t r = row0 + el;
     const bool live = r < a.n;
@@ -474,6 +486,11 @@ __global__ void __launch_bounds__(kT, 2) edge_score_stream64_kernel(ScoreArgs a,
     const int ep = wave & 1, hh = wave >> 1;
     const int kh = lane >> 5, l31 = lane & 31;
     const int64_t row0 = static_cast<int64_t>(blockIdx.x) * kBM2;
+    if (a.dyn_n) {
+        const int64_t live_n = *a.dyn_n;
+        if (live_n < a.n) a.n = live_n;
+        if (row0 >= a.n) return;
+    }
     int el[2], s[2], d[2];
     int64_t eg_id[2];
     bool live[2];
@@ -724,9 +741,14 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
     __shared__ __attribute__((aligned(16))) float bw[2][H];          // b1, w2 for the epilogue
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = lane >> 5, l31 = lane & 31;
+    const int64_t row0 = static_cast<int64_t>(blockIdx.x) * (32 * NW);
+    if (a.dyn_n) {
+        const int64_t live_n = *a.dyn_n;
+        if (live_n < a.n) a.n = live_n;
+        if (row0 >= a.n) return;                                  // (uniform per workgroup, before any barrier)
+    }
     if (!GEMM)
         for (int i = tid; i < H; i += TH) { bw[0][i] = a.b1[i]; bw[1][i] = a.w2[i]; }    // (visible after the first barrier below)
-    const int64_t row0 = static_cast<int64_t>(blockIdx.x) * (32 * NW);
     const int64_t r = row0 + 32 * wave + l31;
     const bool live = r < a.n;
     int s = 0, d = 0;
@@ -1323,8 +1345,10 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
     a.WaT = WaT; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.drop_scale = 1.0f / (1.0f - p_drop); a.drop_thresh = dropout_thresh(p_drop); a.seed = seed; a.epoch = epoch_ptr(); a.site = site;
     a.use_drop = p_drop > 0.f; a.p_out = p_out;
+    a.dyn_n = dyn_edges_ptr();
     int variant = g_score_variant;
     if (variant < 0) variant = (cdiv(E, kBM2) >= 512) ? (H % 128 == 0 ? 4 : 3) : 1;          // 512 = 2 resident workgroups x 256 CUs
+    if (variant == 2 && a.dyn_n) variant = 3;      // the persistent kernel's tile queue is sized on the host
     if (variant == 2 && H % 64 == 0 && N > 0) {
         float* zpart = cv.take<float>(2 * static_cast<size_t>(E));
         unsigned int* ctr = cv.take<unsigned int>(64);

@@ -121,14 +121,18 @@ __global__ void __launch_bounds__(kT) gat_alpha_bwd(const float* __restrict__ a_
 }
 
 // out_order[k] = by_eid[eid[k]]  (re-order a per-edge array into a CSR's entry order)
+// `dyn` (sgs_dyn_edges_set): the entries of a staged parent CSR past the live edge count are stale -- n = min(n, *dyn).  (A drawn
+// subgraph has q < live edges, so its re-orderings are untouched.)
 __global__ void __launch_bounds__(kT) gather_by_eid(const float* __restrict__ by_eid, const int* __restrict__ eid, int64_t n,
-                                                   float* __restrict__ out_order) {
+                                                   float* __restrict__ out_order, const int64_t* __restrict__ dyn) {
     const int64_t k = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (dyn && *dyn < n) n = *dyn;
     if (k < n) out_order[k] = by_eid[eid[k]];
 }
 __global__ void __launch_bounds__(kT) scatter_by_eid(const float* __restrict__ in_order, const int* __restrict__ eid, int64_t n,
-                                                    float* __restrict__ by_eid) {
+                                                    float* __restrict__ by_eid, const int64_t* __restrict__ dyn) {
     const int64_t k = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (dyn && *dyn < n) n = *dyn;
     if (k < n) by_eid[eid[k]] = in_order[k];
 }
 
@@ -175,7 +179,7 @@ int sgs_gather_by_eid(const float* by_eid, const int32_t* eid, int64_t n, float*
     SGS_REQUIRE(n >= 0, SGS_EINVAL, "sgs_gather_by_eid: bad size");
     if (n == 0) return SGS_OK;
     SGS_REQUIRE(by_eid && eid && out_order, SGS_EINVAL, "sgs_gather_by_eid: null pointer");
-    hipLaunchKernelGGL(gather_by_eid, dim3(cdiv(n, kT)), dim3(kT), 0, stream, by_eid, eid, n, out_order);
+    hipLaunchKernelGGL(gather_by_eid, dim3(cdiv(n, kT)), dim3(kT), 0, stream, by_eid, eid, n, out_order, dyn_edges_ptr());
     SGS_LAUNCH_OK();
     return SGS_OK;
 }
@@ -185,7 +189,7 @@ int sgs_scatter_by_eid(const float* in_order, const int32_t* eid, int64_t n, flo
     SGS_REQUIRE(n >= 0, SGS_EINVAL, "sgs_scatter_by_eid: bad size");
     if (n == 0) return SGS_OK;
     SGS_REQUIRE(in_order && eid && by_eid, SGS_EINVAL, "sgs_scatter_by_eid: null pointer");
-    hipLaunchKernelGGL(scatter_by_eid, dim3(cdiv(n, kT)), dim3(kT), 0, stream, in_order, eid, n, by_eid);
+    hipLaunchKernelGGL(scatter_by_eid, dim3(cdiv(n, kT)), dim3(kT), 0, stream, in_order, eid, n, by_eid, dyn_edges_ptr());
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

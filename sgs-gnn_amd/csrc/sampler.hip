@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(kThreads) reduce_partial(const float* __restri
     for (int i = 0; i < kItems; ++i) {
         const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
         if (e < E) {
-            const float v = p[e];
+            const float v = p ? p[e] : 1.f;          // p == nullptr: uniform weights (sgs_sample_topq, random_edge_sampling)
             if (MODE == 0) acc += v;
             else if (MODE == 1) acc = fmaxf(acc, v);
             else acc += expf(v - mx);
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(kThreads) keys_hist0(const float* __restrict__
         for (int i = 0; i < kItems; ++i) {
             const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
             if (e < E) {
-                const float s = sample_prob<MODE>(p[e], Zeps, mx, has_prior ? prior[e] : 0.f, has_prior, one_minus_c, c);
+                const float s = sample_prob<MODE>(p ? p[e] : 1.f, Zeps, mx, has_prior ? prior[e] : 0.f, has_prior, one_minus_c, c);
                 const float nz = noise ? noise[e] : exp_noise_at(seed, stream_id, static_cast<uint64_t>(edge_offset + e));
                 const float key = __fdiv_rn(s, nz);
                 const uint32_t bits = __float_as_uint(key);
@@ -281,7 +281,7 @@ __device__ void scan_blocks_body(uint2* __restrict__ cnt, int64_t nblk) {
 __global__ void __launch_bounds__(kThreads) scan_blocks(uint2* __restrict__ cnt, int64_t nblk) { scan_blocks_body(cnt, nblk); }
 
 // blk_gt / blk_eq: number of keys > T / == T in all chunks before this workgroup's
-__device__ __forceinline__ void compact_body(uint32_t blk_gt, uint32_t blk_eq, const uint32_t* __restrict__ keys, int64_t E, int64_t q,
+__device__ __forceinline__ void compact_body(uint32_t blk_gt, uint32_t blk_eq, const uint32_t* __restrict__ keys, int64_t E, int64_t Ecap, int64_t q,
                                              int64_t ties_override, int64_t eid_offset, const SelectState* __restrict__ st,
                                              const float* __restrict__ p, const int64_t* __restrict__ edge_index,
                                              uint8_t* __restrict__ mask, int mask_aligned,
@@ -317,13 +317,13 @@ __device__ __forceinline__ void compact_body(uint32_t blk_gt, uint32_t blk_eq, c
     // The endpoint columns of this thread's 8 candidates are loaded UNCONDITIONALLY as four 16-byte vectors per row of
     // edge_index when the tile is whole: at the usual 20 % keep rate a predicated 8-byte gather touches nearly every cache
     // line anyway, and at full-graph scale (E = 114.6 M) the streaming form is what HBM delivers at speed.
-    const bool whole = e0 + kItems <= E && sei != nullptr && ((reinterpret_cast<uintptr_t>(edge_index) | (static_cast<uint64_t>(E) * 8)) & 15) == 0;
+    const bool whole = e0 + kItems <= E && sei != nullptr && ((reinterpret_cast<uintptr_t>(edge_index) | (static_cast<uint64_t>(Ecap) * 8)) & 15) == 0;
     int64_t sv[kItems], dv[kItems];
     if (whole) {
 #pragma unroll
         for (int j = 0; j < kItems; j += 2) {
             const longlong2 a = *reinterpret_cast<const longlong2*>(edge_index + e0 + j);
-            const longlong2 b = *reinterpret_cast<const longlong2*>(edge_index + E + e0 + j);
+            const longlong2 b = *reinterpret_cast<const longlong2*>(edge_index + Ecap + e0 + j);
             sv[j] = a.x; sv[j + 1] = a.y; dv[j] = b.x; dv[j + 1] = b.y;
         }
     }
@@ -339,9 +339,9 @@ __device__ __forceinline__ void compact_body(uint32_t blk_gt, uint32_t blk_eq, c
                 if (sampled_eid) sampled_eid[pos] = eid_offset + e;
                 if (sei) {
                     sei[pos] = whole ? sv[j] : edge_index[e];
-                    sei[q + pos] = whole ? dv[j] : edge_index[E + e];
+                    sei[q + pos] = whole ? dv[j] : edge_index[Ecap + e];
                 }
-                if (sampled_p) sampled_p[pos] = p[e];
+                if (sampled_p) sampled_p[pos] = p ? p[e] : 1.f;
             }
             bg += isgt;
             be += iseq;
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(kThreads) compact(const uint32_t* __restrict__
                                                    uint8_t* __restrict__ mask, int mask_aligned,
                                                    int64_t* __restrict__ sampled_eid, int64_t* __restrict__ sei,
                                                    float* __restrict__ sampled_p) {
-    compact_body(cnt[blockIdx.x].x, cnt[blockIdx.x].y, keys, E, q, ties_override, eid_offset, st, p, edge_index, mask, mask_aligned,
+    compact_body(cnt[blockIdx.x].x, cnt[blockIdx.x].y, keys, E, E, q, ties_override, eid_offset, st, p, edge_index, mask, mask_aligned,
                  sampled_eid, sei, sampled_p);
 }
 
@@ -376,6 +376,18 @@ constexpr int kSmallBlocks = 1024;
 constexpr int kHistGrid = 2048;        // workgroups of the histogram passes on the large-E path (grid-stride over chunks)     // small path when E <= 1024 chunks (2 M candidate edges)
 
 struct SelPart { uint32_t prefix, k_rem; };
+
+// sgs_dyn_edges_set: the live candidate count comes from a device word; the launch was sized for the capacity.  Returns false
+// for a workgroup that has no chunk of the live range (it leaves at once: it has no part in the recomputed reductions either).
+__device__ __forceinline__ bool dyn_range(const int64_t* __restrict__ dynE, int64_t& E, int64_t& nblk) {
+    if (dynE) {
+        const int64_t live = *dynE;               // never more than the capacity the launch was sized for
+        if (live < E) E = live;
+        nblk = (E + kChunk - 1) / kChunk;
+        return static_cast<int64_t>(blockIdx.x) < nblk;
+    }
+    return true;
+}
 
 template <int MODE>   // 1: max, otherwise sum (fixed tree, as reduce_final); result in every thread
 __device__ __forceinline__ float final_reduce_all(const float* __restrict__ part, int64_t n, float* red) {
@@ -437,16 +449,18 @@ __device__ __forceinline__ uint2 select_digit_local(const uint32_t* __restrict__
 // first kernel of a draw: per-chunk partial (sum for LEARNED, max for PRIOR) + clears the three digit histograms
 template <int MODE>
 __global__ void __launch_bounds__(kThreads) small_reduce_first(const float* __restrict__ p, int64_t E, float* __restrict__ part,
-                                                              uint32_t* __restrict__ hist3) {
+                                                              uint32_t* __restrict__ hist3, const int64_t* __restrict__ dynE) {
     __shared__ float red[kThreads / 64];
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < 3 * kBins; i += gridDim.x * kThreads) hist3[i] = 0;
+    int64_t nblk_ = 0;
+    if (!dyn_range(dynE, E, nblk_)) return;
     const int64_t base = static_cast<int64_t>(blockIdx.x) * kChunk;
     float acc = (MODE == 1) ? -INFINITY : 0.f;
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
         const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
         if (e < E) {
-            const float v = p[e];
+            const float v = p ? p[e] : 1.f;
             if (MODE == 1) acc = fmaxf(acc, v);
             else acc += v;
         }
@@ -462,8 +476,9 @@ __global__ void __launch_bounds__(kThreads) small_reduce_first(const float* __re
 
 // PRIOR only: per-chunk partial of sum(exp(p - max)); the max is re-reduced by every workgroup from part_max
 __global__ void __launch_bounds__(kThreads) small_reduce_sumexp(const float* __restrict__ p, int64_t E, const float* __restrict__ part_max,
-                                                               int64_t nblk, float* __restrict__ part_sum) {
+                                                               int64_t nblk, float* __restrict__ part_sum, const int64_t* __restrict__ dynE) {
     __shared__ float red[kThreads / 64];
+    if (!dyn_range(dynE, E, nblk)) return;
     const float mx = final_reduce_all<1>(part_max, nblk, red);
     const int64_t base = static_cast<int64_t>(blockIdx.x) * kChunk;
     float acc = 0.f;
@@ -484,9 +499,11 @@ __global__ void __launch_bounds__(kThreads) small_keys_hist0(const float* __rest
                                                             const uint64_t* __restrict__ epoch, int64_t E, float one_minus_c, float c,
                                                             const float* __restrict__ part_sum, const float* __restrict__ part_max,
                                                             int64_t nblk, float* __restrict__ scal, uint32_t* __restrict__ keys,
-                                                            float* __restrict__ keys_out, uint32_t* __restrict__ hist0) {
+                                                            float* __restrict__ keys_out, uint32_t* __restrict__ hist0,
+                                                            const int64_t* __restrict__ dynE) {
     __shared__ uint32_t lh[kBins];
     __shared__ float red[kThreads / 64];
+    if (!dyn_range(dynE, E, nblk)) return;
     for (int i = threadIdx.x; i < kBins; i += kThreads) lh[i] = 0;
     seed = fold_epoch(seed, epoch);
     const float mx = (MODE == SGS_SAMPLE_PRIOR) ? final_reduce_all<1>(part_max, nblk, red) : 0.f;
@@ -499,7 +516,7 @@ __global__ void __launch_bounds__(kThreads) small_keys_hist0(const float* __rest
     for (int i = 0; i < kKeyItems; ++i) {
         const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
         if (e < E) {
-            const float s = sample_prob<MODE>(p[e], Zeps, mx, has_prior ? prior[e] : 0.f, has_prior, one_minus_c, c);
+            const float s = sample_prob<MODE>(p ? p[e] : 1.f, Zeps, mx, has_prior ? prior[e] : 0.f, has_prior, one_minus_c, c);
             const float nz = noise ? noise[e] : exp_noise_at(seed, stream_id, static_cast<uint64_t>(e));
             const float key = __fdiv_rn(s, nz);
             const uint32_t bits = __float_as_uint(key);
@@ -520,8 +537,10 @@ __global__ void __launch_bounds__(kThreads) small_keys_hist0(const float* __rest
 __global__ void __launch_bounds__(kThreads) small_hist_next(const uint32_t* __restrict__ keys, int64_t E, int shift, uint32_t digit_mask,
                                                            int prev_shift, int first, uint32_t q, const uint32_t* __restrict__ hist_prev,
                                                            const SelPart* __restrict__ sel_in, SelPart* __restrict__ sel_out,
-                                                           uint32_t* __restrict__ hist) {
+                                                           uint32_t* __restrict__ hist, const int64_t* __restrict__ dynE) {
     __shared__ uint32_t lh[kBins];
+    int64_t nblk_ = 0;
+    if (!dyn_range(dynE, E, nblk_)) return;
     for (int i = threadIdx.x; i < kBins; i += kThreads) lh[i] = 0;
     const uint32_t k = first ? q : sel_in->k_rem;
     const uint32_t pre = first ? 0u : sel_in->prefix;
@@ -550,8 +569,10 @@ __global__ void __launch_bounds__(kThreads) small_hist_next(const uint32_t* __re
 __global__ void __launch_bounds__(kThreads) small_count(const uint32_t* __restrict__ keys, int64_t E, uint32_t q,
                                                        const uint32_t* __restrict__ hist2, const SelPart* __restrict__ sel_in,
                                                        SelectState* __restrict__ st, uint2* __restrict__ cnt, const float* __restrict__ scal,
-                                                       float* __restrict__ stats) {
+                                                       float* __restrict__ stats, const int64_t* __restrict__ dynE) {
     __shared__ int red[2 * (kThreads / 64)];
+    int64_t nblk_ = 0;
+    if (!dyn_range(dynE, E, nblk_)) return;
     const uint32_t k = sel_in->k_rem;
     const uint2 f = select_digit_local(hist2, k);
     const uint32_t T = sel_in->prefix | (f.x << kShift2);
@@ -594,9 +615,12 @@ __global__ void __launch_bounds__(kThreads) small_compact(const uint32_t* __rest
                                                          const uint2* __restrict__ cnt, const float* __restrict__ p,
                                                          const int64_t* __restrict__ edge_index, uint8_t* __restrict__ mask, int mask_aligned,
                                                          int64_t* __restrict__ sampled_eid, int64_t* __restrict__ sei,
-                                                         float* __restrict__ sampled_p) {
+                                                         float* __restrict__ sampled_p, const int64_t* __restrict__ dynE) {
     __shared__ int red[2 * (kThreads / 64)];
     __shared__ uint32_t pre[2];
+    const int64_t Ecap = E;                       // row stride of edge_index (the capacity under sgs_dyn_edges_set)
+    int64_t nblk_ = 0;
+    if (!dyn_range(dynE, E, nblk_)) return;
     int g = 0, e = 0;
     for (int i = threadIdx.x; i < static_cast<int>(blockIdx.x); i += kThreads) { g += static_cast<int>(cnt[i].x); e += static_cast<int>(cnt[i].y); }
     g = wave_sum_int_all(g);
@@ -610,7 +634,7 @@ __global__ void __launch_bounds__(kThreads) small_compact(const uint32_t* __rest
         pre[1] = static_cast<uint32_t>(Q);
     }
     __syncthreads();
-    compact_body(pre[0], pre[1], keys, E, q, int64_t(-1), int64_t(0), st, p, edge_index, mask, mask_aligned, sampled_eid, sei, sampled_p);
+    compact_body(pre[0], pre[1], keys, E, Ecap, q, int64_t(-1), int64_t(0), st, p, edge_index, mask, mask_aligned, sampled_eid, sei, sampled_p);
 }
 
 // counts[0] = #keys > threshold, counts[1] = #keys == threshold in this shard (before the scan).
@@ -646,8 +670,19 @@ __global__ void select_all(int64_t E, const float* __restrict__ p, const int64_t
     if (value) {
         if (sampled_eid) sampled_eid[e] = e;
         if (sei) { sei[e] = edge_index[e]; sei[E + e] = edge_index[E + e]; }
-        if (sampled_p) sampled_p[e] = p[e];
+        if (sampled_p) sampled_p[e] = p ? p[e] : 1.f;
     }
+}
+
+// out[0, j] = edge_index[0, idx[j]], out[1, j] = edge_index[1, idx[j]]  (sampling.py:161-163: edge_index[:, sampled_indices])
+__global__ void gather_columns_kernel(const int64_t* __restrict__ edge_index, int64_t E, const int64_t* __restrict__ idx, int64_t q,
+                                      int64_t* __restrict__ out) {
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (j >= q) return;
+    const int64_t e = idx[j];
+    const bool ok = e >= 0 && e < E;                  // out-of-range indices give (-1, -1) columns instead of a fault
+    out[j] = ok ? edge_index[e] : int64_t(-1);
+    out[q + j] = ok ? edge_index[E + e] : int64_t(-1);
 }
 
 __global__ void exp_noise_kernel(uint64_t seed, uint64_t stream_id, const uint64_t* __restrict__ epoch, int64_t E, float* __restrict__ noise) {
@@ -722,11 +757,13 @@ __global__ void __launch_bounds__(kThreads) st_bwd_final(const float* __restrict
 }
 
 __global__ void st_bwd_dense(const float* __restrict__ S, const float* __restrict__ stats, float a, int64_t E,
-                             float* __restrict__ dp) {
+                             float* __restrict__ dp, const int64_t* __restrict__ dynE) {
     const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (k >= E) return;
     const float Zeps = stats[0] + 1e-12f;
-    dp[k] = -(a / (Zeps * Zeps)) * S[0];
+    // under sgs_dyn_edges_set the entries between the live count and the capacity are not edges: exactly zero gradient
+    dp[k] = (dynE && k >= *dynE) ? 0.f : -(a / (Zeps * Zeps)) * S[0];
+
 }
 
 template <bool HAS_PRIOR>
@@ -796,7 +833,8 @@ int sgs_sample_topq(int mode, const float* p, const float* prior, double degree_
                 "sgs_sample_topq: cannot sample q=%lld > E=%lld edges without replacement", (long long)q, (long long)E);
     SGS_REQUIRE(E < (int64_t(1) << 32), SGS_EINVAL, "sgs_sample_topq: E=%lld exceeds 2^32-1", (long long)E);
     if (E == 0) return SGS_OK;
-    SGS_REQUIRE(p && mask, SGS_EINVAL, "sgs_sample_topq: null p/mask");
+    SGS_REQUIRE(mask, SGS_EINVAL, "sgs_sample_topq: null mask");
+    SGS_REQUIRE(p || (mode == SGS_SAMPLE_LEARNED && !prior), SGS_EINVAL, "sgs_sample_topq: p == NULL (uniform weights) needs mode LEARNED and no prior");
     SGS_REQUIRE(!sampled_edge_index || edge_index, SGS_EINVAL, "sgs_sample_topq: edge_index required for sampled_edge_index");
     SGS_REQUIRE(ws && ws_bytes >= sgs_sample_topq_workspace_bytes(E), SGS_EWORKSPACE,
                 "sgs_sample_topq: workspace too small (%zu < %zu)", ws_bytes, sgs_sample_topq_workspace_bytes(E));
@@ -821,27 +859,30 @@ int sgs_sample_topq(int mode, const float* p, const float* prior, double degree_
     const float c = static_cast<float>(degree_bias_coef);
     const int mask_aligned = (reinterpret_cast<uintptr_t>(mask) & 7) == 0;
 
+    const int64_t* dynE = dyn_edges_ptr();
+    SGS_REQUIRE(!dynE || (nblk <= kSmallBlocks && q > 0 && q < E), SGS_EINVAL,
+                "sgs_sample_topq: a dynamic edge count (sgs_dyn_edges_set) needs 0 < q < capacity <= %lld", (long long)kSmallBlocks * kChunk);
     if (nblk <= kSmallBlocks && q > 0 && q < E) {
         // fused small-E path: 6 / 7 launches (see "fused small-E path" above); same arithmetic, same results
         const uint32_t q32 = static_cast<uint32_t>(q);
         uint32_t *h0 = hist3, *h1 = hist3 + kBins, *h2 = hist3 + 2 * kBins;
         const dim3 kgrid(static_cast<unsigned>(cdiv(E, kThreads * kKeyItems)));
         if (mode == SGS_SAMPLE_LEARNED) {
-            hipLaunchKernelGGL(small_reduce_first<0>, grid, blk, 0, stream, p, E, part, hist3);
+            hipLaunchKernelGGL(small_reduce_first<0>, grid, blk, 0, stream, p, E, part, hist3, dynE);
             hipLaunchKernelGGL(small_keys_hist0<SGS_SAMPLE_LEARNED>, kgrid, blk, 0, stream, p, prior, noise, seed, stream_id, epoch_ptr(), E,
-                               one_minus_c, c, part, static_cast<const float*>(nullptr), nblk, scal, keys, keys_out, h0);
+                               one_minus_c, c, part, static_cast<const float*>(nullptr), nblk, scal, keys, keys_out, h0, dynE);
         } else {
-            hipLaunchKernelGGL(small_reduce_first<1>, grid, blk, 0, stream, p, E, part, hist3);
-            hipLaunchKernelGGL(small_reduce_sumexp, grid, blk, 0, stream, p, E, part, nblk, part2);
+            hipLaunchKernelGGL(small_reduce_first<1>, grid, blk, 0, stream, p, E, part, hist3, dynE);
+            hipLaunchKernelGGL(small_reduce_sumexp, grid, blk, 0, stream, p, E, part, nblk, part2, dynE);
             hipLaunchKernelGGL(small_keys_hist0<SGS_SAMPLE_PRIOR>, kgrid, blk, 0, stream, p, static_cast<const float*>(nullptr), noise, seed,
-                               stream_id, epoch_ptr(), E, one_minus_c, c, part2, part, nblk, scal, keys, keys_out, h0);
+                               stream_id, epoch_ptr(), E, one_minus_c, c, part2, part, nblk, scal, keys, keys_out, h0, dynE);
         }
         hipLaunchKernelGGL(small_hist_next, grid, blk, 0, stream, keys, E, kShift1, kMask1, kShift0, 1, q32, h0,
-                           static_cast<const SelPart*>(nullptr), sel, h1);
-        hipLaunchKernelGGL(small_hist_next, grid, blk, 0, stream, keys, E, kShift2, kMask2, kShift1, 0, q32, h1, sel, sel + 1, h2);
-        hipLaunchKernelGGL(small_count, grid, blk, 0, stream, keys, E, q32, h2, sel + 1, st, cnt, scal, stats);
+                           static_cast<const SelPart*>(nullptr), sel, h1, dynE);
+        hipLaunchKernelGGL(small_hist_next, grid, blk, 0, stream, keys, E, kShift2, kMask2, kShift1, 0, q32, h1, sel, sel + 1, h2, dynE);
+        hipLaunchKernelGGL(small_count, grid, blk, 0, stream, keys, E, q32, h2, sel + 1, st, cnt, scal, stats, dynE);
         hipLaunchKernelGGL(small_compact, grid, blk, 0, stream, keys, E, q, st, cnt, p, edge_index, mask, mask_aligned, sampled_eid,
-                           sampled_edge_index, sampled_p);
+                           sampled_edge_index, sampled_p, dynE);
         SGS_LAUNCH_OK();
         return SGS_OK;
     }
@@ -1003,6 +1044,16 @@ int sgs_sampler_shard_compact(const uint32_t* keys, int64_t E, const void* state
     return SGS_OK;
 }
 
+int sgs_gather_columns(const int64_t* edge_index, int64_t E, const int64_t* idx, int64_t q, int64_t* out, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(E >= 0 && q >= 0, SGS_EINVAL, "sgs_gather_columns: bad sizes");
+    if (q == 0) return SGS_OK;
+    SGS_REQUIRE(edge_index && idx && out, SGS_EINVAL, "sgs_gather_columns: null pointer");
+    hipLaunchKernelGGL(gather_columns_kernel, dim3(cdiv(q, 256)), dim3(256), 0, stream, edge_index, E, idx, q, out);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
 int sgs_st_weights_fwd(const float* p, const float* prior, double degree_bias_coef, const float* stats,
                        const int64_t* sampled_eid, int64_t E, int64_t q, float* w, sgs_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -1051,7 +1102,7 @@ int sgs_st_weights_bwd(const float* p, const float* prior, double degree_bias_co
                                sampled_eid, grad_w, q, part);
         hipLaunchKernelGGL(st_bwd_final, dim3(1), dim3(kThreads), 0, stream, part, nblk, S);
     }
-    hipLaunchKernelGGL(st_bwd_dense, dim3(cdiv(E, 256)), dim3(256), 0, stream, S, stats, a, E, grad_p);
+    hipLaunchKernelGGL(st_bwd_dense, dim3(cdiv(E, 256)), dim3(256), 0, stream, S, stats, a, E, grad_p, dyn_edges_ptr());
     if (q > 0) {
         if (prior)
             hipLaunchKernelGGL(st_bwd_sparse<true>, dim3(cdiv(q, 256)), dim3(256), 0, stream, p, prior, one_minus_c, c, a,

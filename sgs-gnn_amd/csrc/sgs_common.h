@@ -49,6 +49,13 @@ __device__ __forceinline__ uint64_t fold_epoch(uint64_t seed, const uint64_t* __
     return epoch ? seed + 0x9E3779B97F4A7C15ULL * (*epoch) : seed;
 }
 
+// ---------------------------------------------------------------- dynamic candidate-edge count (HIP-graph replay)
+// Sizes are kernel arguments by value, which a captured graph freezes.  While a device word is registered
+// (sgs_dyn_edges_set), sgs_sample_topq and sgs_edge_score_fwd read the number of candidate edges E from it at run time and
+// treat their `E` argument as the capacity (grid size, row stride of edge_index, buffer sizes): ONE captured step then
+// serves partitions of any size.  nullptr (default) = sizes used as given.
+const int64_t* dyn_edges_ptr();
+
 // ---------------------------------------------------------------- zero fill as a KERNEL
 // hipMemsetAsync is deliberately not used anywhere in this library: captured into a HIP graph it becomes a memset
 // node, and on replay (ROCm 7.2 / gfx950) those were observed not to stay ordered with the neighbouring kernel nodes

@@ -175,6 +175,65 @@ class ResidentPartitions:
     def __getitem__(self, i):
         return self.batches[i]
 
+    # ------------------------------------------------------------------ on-disk partition cache
+    # The reference caches the METIS result through ClusterData(save_dir=...) (main.py:59-63; PyG 2.3.1 writes
+    # `save_dir/partition_<P>.pt` = (adj, partptr, perm)) and re-slices every batch from it on the CPU.  Here the cache holds the
+    # result of that slicing too, as ONE tensor-only safetensors file `save_dir/sgs_partitions_<P>.safetensors`:
+    #   perm [N] i64        original node id of new node i (nodes grouped by partition; PyG's `perm`)
+    #   node_ptr [P+1] i64  partition p owns new nodes node_ptr[p]:node_ptr[p+1]          (PyG's `partptr`)
+    #   edge_ptr [P+1] i64  ... and intra-partition edges edge_ptr[p]:edge_ptr[p+1]
+    #   x [N,F] f32, y [N] i64, train_mask / val_mask / test_mask [N] u8     node attributes in new order
+    #   edge_index [2,E'] i64   intra-partition edges, partition-LOCAL node ids, row-sorted inside each partition
+    #   prob [E'] f32           the edge prior sliced like edge_index (add_degree / add_ER output)
+    # metadata: format = "sgs-partitions-v1", num_parts, dropped_edges.  Nothing in the file is executable.
+    FORMAT = "sgs-partitions-v1"
+
+    @staticmethod
+    def cache_path(save_dir: str, num_parts: int) -> str:
+        import os
+        return os.path.join(save_dir, f"sgs_partitions_{int(num_parts)}.safetensors")
+
+    def save(self, save_dir: str) -> str:
+        import os
+        from safetensors.torch import save_file
+        os.makedirs(save_dir, exist_ok=True)
+        cat = lambda k, dim=0: torch.cat([getattr(b, k) for b in self.batches], dim=dim).contiguous().cpu()      # noqa: E731
+        t = dict(perm=self.perm.cpu(), node_ptr=self.node_ptr.cpu(), edge_ptr=self.edge_ptr.cpu(), x=cat("x"), y=cat("y"),
+                 train_mask=cat("train_mask").to(torch.uint8), val_mask=cat("val_mask").to(torch.uint8),
+                 test_mask=cat("test_mask").to(torch.uint8), edge_index=cat("edge_index", 1), prob=cat("prob"))
+        path = self.cache_path(save_dir, self.num_parts)
+        save_file(t, path, metadata={"format": self.FORMAT, "num_parts": str(self.num_parts), "dropped_edges": str(self.dropped_edges)})
+        return path
+
+    @classmethod
+    def load(cls, save_dir: str, num_parts: int, device="cuda:0", shuffle=False, seed=0) -> "ResidentPartitions":
+        """Rebuild the resident partition tables from `save()`'s file: memory-mapped read, one host-to-device copy per tensor,
+        then per-partition views (no re-partitioning, no prior recomputation)."""
+        from safetensors import safe_open
+        dev = torch.device(device)
+        path = cls.cache_path(save_dir, num_parts)
+        with safe_open(path, framework="pt", device="cpu") as f:
+            meta = f.metadata() or {}
+            if meta.get("format") != cls.FORMAT or int(meta.get("num_parts", -1)) != int(num_parts):
+                raise ValueError(f"{path}: not a {cls.FORMAT} cache for {num_parts} partitions")
+            t = {k: f.get_tensor(k).to(dev) for k in f.keys()}
+        self = cls.__new__(cls)
+        P = int(num_parts)
+        self.num_parts, self.perm, self.node_ptr, self.edge_ptr = P, t["perm"], t["node_ptr"], t["edge_ptr"]
+        self.dropped_edges = int(meta.get("dropped_edges", 0))
+        nptr, eptr = t["node_ptr"].tolist(), t["edge_ptr"].tolist()
+        if len(nptr) != P + 1 or len(eptr) != P + 1 or nptr[-1] != t["x"].shape[0] or eptr[-1] != t["edge_index"].shape[1]:
+            raise ValueError(f"{path}: inconsistent partition pointers")
+        tm, vm, sm = t["train_mask"].bool(), t["val_mask"].bool(), t["test_mask"].bool()
+        self.batches = []
+        for p in range(P):
+            a, b, ea, eb = nptr[p], nptr[p + 1], eptr[p], eptr[p + 1]
+            self.batches.append(Batch(x=t["x"][a:b], edge_index=t["edge_index"][:, ea:eb].contiguous(), y=t["y"][a:b], train_mask=tm[a:b],
+                                      val_mask=vm[a:b], test_mask=sm[a:b], prob=t["prob"][ea:eb], part=p, node_ids=t["perm"][a:b]))
+        self.shuffle = shuffle
+        self._gen = torch.Generator().manual_seed(seed)
+        return self
+
     def __iter__(self):
         order = torch.randperm(self.num_parts, generator=self._gen).tolist() if self.shuffle else range(self.num_parts)
         for i in order:

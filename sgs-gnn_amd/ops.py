@@ -127,6 +127,22 @@ def set_rng_epoch_buffer(epoch) -> None:
     _rng_epoch = epoch
 
 
+_dyn_edges = None       # keeps the registered device word alive
+
+
+def set_dyn_edges(word) -> None:
+    """Register (or clear with None) the device word holding the live candidate-edge count (sgs_dyn_edges_set): kernels over the
+    candidate edges launched while it is registered -- i.e. captured into a HIP graph -- take their size from it at run time."""
+    global _dyn_edges
+    L = _lib.lib()
+    if word is not None:
+        _need_gpu(word)
+        if word.dtype != torch.int64 or word.numel() != 1:
+            raise RuntimeError("sgs_gnn_amd: the dynamic edge count is one int64 device word")
+    _lib.check(L.sgs_dyn_edges_set(None if word is None else word.data_ptr()), "sgs_dyn_edges_set")
+    _dyn_edges = word
+
+
 def exp_noise(seed: int, stream_id: int, E: int, device) -> torch.Tensor:
     L = _lib.lib()
     out = torch.empty(E, dtype=torch.float32, device=device)
@@ -150,11 +166,13 @@ class SampleResult:
 
 def sample_topq(mode: int, p: torch.Tensor, prior, c: float, q: int, edge_index, noise=None, seed: int = 0,
                 stream_id: int = 0, want_keys: bool = False, want_p: bool = True) -> SampleResult:
-    """K0/K2/K3 (see sgs_sample_topq).  p [E] f32; prior [E] f32 or None; edge_index [2,E] i64."""
+    """K0/K2/K3 (see sgs_sample_topq).  p [E] f32 (None: uniform weights); prior [E] f32 or None; edge_index [2,E] i64."""
     L = _lib.lib()
     _need_gpu(p, prior, edge_index, noise)
-    E = p.numel()
-    dev = p.device
+    if p is None and edge_index is None:
+        raise RuntimeError("sample_topq: uniform weights (p=None) need edge_index for the number of candidates")
+    E = p.numel() if p is not None else edge_index.shape[1]
+    dev = p.device if p is not None else edge_index.device
     if q > E:
         raise RuntimeError(f"cannot sample q={q} > E={E} edges without replacement")
     r = SampleResult()
@@ -162,7 +180,7 @@ def sample_topq(mode: int, p: torch.Tensor, prior, c: float, q: int, edge_index,
     r.mask = torch.empty(E, dtype=torch.bool, device=dev)
     r.eid = torch.empty(q, dtype=torch.int64, device=dev)
     r.edge_index = torch.empty(2, q, dtype=torch.int64, device=dev) if edge_index is not None else None
-    r.p = torch.empty(q, dtype=torch.float32, device=dev) if want_p else None
+    r.p = torch.empty(q, dtype=torch.float32, device=dev) if (want_p and p is not None) else None
     r.stats = torch.empty(4, dtype=torch.float32, device=dev)
     r.keys = torch.empty(E, dtype=torch.float32, device=dev) if want_keys else None
     nws = L.sgs_sample_topq_workspace_bytes(E)
@@ -172,6 +190,17 @@ def sample_topq(mode: int, p: torch.Tensor, prior, c: float, q: int, edge_index,
                                  _ptr(r.mask), _ptr(r.eid), _ptr(r.edge_index), _ptr(r.p), _ptr(r.stats),
                                  _ptr(r.keys), ws.data_ptr(), ws.numel(), _stream()), "sgs_sample_topq")
     return r
+
+
+def gather_columns(edge_index: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """edge_index[:, idx] (sampling.py:163) as one launch."""
+    L = _lib.lib()
+    _need_gpu(edge_index, idx)
+    q = idx.numel()
+    out = torch.empty(2, q, dtype=torch.int64, device=edge_index.device)
+    _lib.check(L.sgs_gather_columns(_ptr(edge_index, torch.int64), edge_index.shape[1], _ptr(idx.contiguous(), torch.int64), q, _ptr(out),
+                                    _stream()), "sgs_gather_columns")
+    return out
 
 
 class _STWeights(torch.autograd.Function):

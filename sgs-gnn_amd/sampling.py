@@ -55,8 +55,13 @@ def gumbel_softmax_sampling(batch, edge_probs, edge_index, q=500, temperature=1.
     return r.mask, w
 
 
-def random_edge_sampling(edge_index, q):
-    """sampling.py:159-163."""
-    num_edges = edge_index.shape[1]
-    sampled_indices = torch.randperm(num_edges, device=edge_index.device)[:q]
-    return edge_index[:, sampled_indices]
+def random_edge_sampling(edge_index, q, *, perm=None):
+    """sampling.py:159-163: `edge_index[:, torch.randperm(E)[:q]]`, a uniformly random q-subset of the columns.
+    On the device the subset is drawn by the sampler with uniform weights (an exponential race with equal weights IS a uniform
+    draw without replacement; noise from the process-wide noise clock, `manual_seed`) and emitted in ORIGINAL edge order -- the
+    reference's column order is the permutation's, which no consumer depends on (every GNN layer sums over incoming edges).
+    `perm` (parity hook): an explicit permutation of range(E); the result is then exactly `edge_index[:, perm[:q]]`."""
+    if perm is not None:
+        return ops.gather_columns(edge_index.contiguous(), perm[:q].to(edge_index.device))
+    seed, sid = _NoiseClock.next()
+    return ops.sample_topq(ops.SAMPLE_LEARNED, None, None, 0.0, q, edge_index.contiguous(), seed=seed, stream_id=sid, want_p=False).edge_index

@@ -192,7 +192,7 @@ def _train(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edg
     if getattr(args, "sgs_hipgraph", False) and mode == 'learned' and not noise and trace is None and _fused_ce_ok(criterion):
         from .stepgraph import StepGraphs               # opt-in: replay captured HIP graphs of each partition's step
         graphs = StepGraphs.attach(model, pipeline, args, criterion, q, use_checkpoint,
-                                   optimizers=(optimizer_edge_prob, optimizer_gnn), sync=sync)
+                                   optimizers=(optimizer_edge_prob, optimizer_gnn), sync=sync, loader=cluster_loader)
 
     try:
         return _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, optimizer,

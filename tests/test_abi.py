@@ -105,3 +105,14 @@ def test_synthetic_stream_mirrors_reference_partition_mix():
     rev = ei[1] * 300 + ei[0]
     assert torch.equal(torch.sort(rev).values, key)                           # undirected
     assert abs(float(b.prob.sum()) - 1.0) < 1e-4
+
+
+def test_library_contains_no_memset_nodes():
+    """Round-1 GPU fault: hipMemsetAsync captured into a HIP graph became a memset node that did not stay
+    ordered with the neighbouring kernel nodes on replay (ROCm 7.2 / gfx950) -> garbage indices -> memory fault.  The library
+    zero-fills with kernels instead; this guards the fix: libsgs_hip.so must not import any hipMemset* / hipMemcpy*Async entry."""
+    import subprocess
+    from sgs_gnn_amd import _lib
+    out = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    bad = [ln for ln in out.splitlines() if "hipMemset" in ln or "hipMemcpy" in ln]
+    assert not bad, bad

@@ -211,3 +211,33 @@ def test_rng_epoch_buffer_shifts_every_seed(ops):
     y_ref = ops.gcn_propagate(X, nm, None, ops.ACT_RELU_DROPOUT, 0.3, s5, 3)
     assert torch.equal(y_epoch, y_ref)
     assert not torch.equal(y_epoch, ops.gcn_propagate(X, nm, None, ops.ACT_RELU_DROPOUT, 0.3, seed, 3))
+
+
+def test_random_edge_sampling_reference_case_and_uniform_draw(ops):
+    """a13, sampling.py:159-163.  (i) With the permutation the REFERENCE drew (tests/golden/sampler.pt, recorded from torch.randperm
+    under the reference's generator state) the device op returns the reference's output exactly.  (ii) Without it the device draws
+    a uniformly random q-subset itself: q distinct columns of edge_index in edge order, reproducible under manual_seed, different
+    from call to call, and uniform (every edge kept with probability q/E: checked on the mean keep rate per decile of edge ids)."""
+    import sgs_gnn_amd as S
+    for c in load_golden("sampler.pt")["randperm"]:
+        out = S.random_edge_sampling(c["edge_index"].to(DEV), c["q"], perm=c["perm"].to(DEV))
+        assert torch.equal(out.cpu(), c["out"])
+        assert torch.equal(out.cpu(), O.random_edge_sampling(c["edge_index"], c["q"], c["perm"]))
+    E, q = 200_000, 40_000
+    ei = torch.stack([torch.arange(E), torch.arange(E) * 7 % 1013]).to(DEV)          # column e is identifiable by its first row
+    S.manual_seed(5)
+    a = S.random_edge_sampling(ei, q)
+    b = S.random_edge_sampling(ei, q)
+    S.manual_seed(5)
+    a2 = S.random_edge_sampling(ei, q)
+    assert a.shape == (2, q) and torch.equal(a, a2) and not torch.equal(a, b)
+    ida = a[0].cpu()
+    assert bool((ida[1:] > ida[:-1]).all())                                             # distinct, in edge order
+    assert torch.equal(a[1].cpu(), ida * 7 % 1013)                                      # whole columns
+    keep = torch.zeros(E)
+    for _ in range(8):
+        keep[S.random_edge_sampling(ei, q)[0].cpu()] += 1
+    rate = keep.view(10, -1).mean(1) / 8
+    assert float((rate - q / E).abs().max()) < 0.01                                     # sd of a decile's rate over 8 draws ~ 1e-3
+    with pytest.raises(RuntimeError):
+        S.random_edge_sampling(ei, E + 1)

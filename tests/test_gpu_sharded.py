@@ -172,7 +172,7 @@ def test_data_parallel_global_gate_keeps_replicas_identical():
         assert bool(torch.isfinite(a).all())
 
 
-@pytest.mark.parametrize("hipgraph", [False])
+@pytest.mark.parametrize("hipgraph", [False, True])
 def test_data_parallel_uneven_shards_finish_with_null_steps(hipgraph):
     """Ranks with different step counts (4 usable batches on rank 0; 3 on rank 1, one of them without train nodes -> 2 steps): the
     epoch agrees on the longest shard and the short rank joins the remaining steps' collectives with zero gradients
@@ -201,8 +201,8 @@ def test_data_parallel_uneven_shards_finish_with_null_steps(hipgraph):
 def test_data_parallel_train_keeps_replicas_identical(hipgraph):
     """N > 1 on the partition stream: per-rank batches, one flat gradient all-reduce per step, the scorer's
     optimiser steps on every rank iff any rank's gate chose 'learned' -> replicas remain bit-identical.
-    hipgraph=True: the same with each rank replaying its partitions' steps from captured HIP graphs
-    (epoch 0 eager, epoch 1 capture, epochs 2-3 replay); the collectives stay between the replays."""
+    hipgraph=True: the same with each rank replaying its partitions' steps from captured HIP graphs (every step a replay, from
+    the first one on); the collectives stay between the replays."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -40,47 +40,121 @@ def test_unsampled_partitions_replay_equals_eager_bitwise(capturable):
     """capturable=True: the optimiser steps are recorded at the end of the backward graphs (no eager launch per step)."""
     import sgs_gnn_amd as S
     crit = torch.nn.CrossEntropyLoss()
-    bs = _batches(S, [900, 1500, 700])
-    q = 5000                                           # every partition below q: no draws, dropout 0 -> deterministic
+    # every partition below q: no draws, dropout 0 -> deterministic.  Sizes: a replayed step runs the kernels chosen for the slot's
+    # CAPACITY, an eager step those chosen for the partition's own size (sgs_spmm_csr: a workgroup per row from 16 entries per
+    # row on); all of these lie on the same side of that switch, so the arithmetic is the same, in the same order.
+    bs = _batches(S, [2500, 3300, 2100])
+    q = 5000
     m1, og1, oe1 = _setup(S, 0.0, capturable=capturable)
     m2, og2, oe2 = _setup(S, 0.0, capturable=capturable)
     m2.load_state_dict(copy.deepcopy(m1.state_dict()))
     r1, r2 = [], []
-    for ep in range(4):                                # epoch 0 eager warm-up, 1 capture, 2-3 replay
+    for ep in range(4):                                # every step of the graph-mode run is a replay, the very first included
         r1.append(S.train(_args(), ep, 10, m1, og1, oe1, None, crit, bs, q=q))
         r2.append(S.train(_args(sgs_hipgraph=True), ep, 10, m2, og2, oe2, None, crit, bs, q=q))
     assert r1 == r2
     for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert torch.equal(p1, p2), n1
-    assert len(m2._sgs_stepgraphs.table) == 3
-    assert (m2._sgs_stepgraphs.optimizers is not None) == capturable
+    sg = m2._sgs_stepgraphs
+    assert sg.captures == 2 and len(sg.slots[False]) == 2 and not sg.slots[True]      # ONE capture per slot serves all partitions
+    assert (sg.optimizers is not None) == capturable
     # the RNG epoch word is registered only while a graph-mode train() runs
     assert S.ops._rng_epoch is None
+
+
+def _check_sampled_replay(S, m, a, crit, b, q, pipeline, k, cnt, gl, ll, gr, lr_):
+    """Recompute one replayed sampled step eagerly from the replay's own draws (`k`: the slot's kept views, already cut to the
+    partition's E edges / N nodes) and compare outputs, both losses and both branches' gradients."""
+    from sgs_gnn_amd.training import _ce, learned_loss, SampledForward
+    ops = S.ops
+    N = b.x.shape[0]
+    params = list(m.parameters())
+    assert k["eid"].numel() == q and bool((k["eid"][1:] > k["eid"][:-1]).all())
+    assert int(k["eid"][-1]) < b.edge_index.shape[1]
+    assert torch.equal(k["sampled_edge_index"], b.edge_index[:, k["eid"]])
+    for p in params:
+        p.grad = None
+    sc = m.edge_prob_mlp
+    st = SampledForward()
+    st.rsei, st.sampled_edge_index = k["rsei"], k["sampled_edge_index"]
+    if pipeline == "two_pass":
+        with torch.no_grad():
+            pf = sc(b.x, b.edge_index, k["rsei"]).squeeze()
+    else:
+        pf = sc(b.x, b.edge_index, k["rsei"]).squeeze()
+    assert torch.allclose(pf.detach(), k["edge_probs_full"], rtol=1e-5, atol=1e-6)
+    if pipeline == "hybrid":
+        act = getattr(sc, "last_active", None)
+        if act is not None:
+            act.set(k["eid"], ops.get_graph(k["sampled_edge_index"], N))
+        w = pf.index_select(0, k["eid"])
+    elif pipeline == "two_pass":
+        w = sc(b.x, k["sampled_edge_index"]).squeeze()
+    else:
+        w = None
+    if w is not None:
+        st.edge_probs_for_loss = w
+        assert torch.allclose(w.detach(), k["w"], rtol=1e-5, atol=1e-6)
+        st.learned_out = m(b, k["sampled_edge_index"], w)
+        assert torch.allclose(st.learned_out.detach(), k["learned_out"], rtol=1e-4, atol=1e-5)
+        loss = learned_loss(a, crit, st, b)
+        loss.backward()
+        assert torch.allclose(loss.detach(), ll, rtol=1e-5, atol=1e-6)
+        for i, p in enumerate(params):
+            if p.grad is None:
+                assert i not in gl
+            else:
+                assert torch.allclose(p.grad, gl[i], rtol=2e-4, atol=2e-6), i
+    # random branch
+    for p in params:
+        p.grad = None
+    ro = m(b, k["rsei"])
+    assert torch.allclose(ro.detach(), k["random_out"], rtol=1e-4, atol=1e-5)
+    lr2 = _ce(crit, ro, b)
+    lr2.backward()
+    assert torch.allclose(lr2.detach(), lr_, rtol=1e-5, atol=1e-6)
+    for i, p in enumerate(params):
+        if p.grad is None:
+            assert i not in gr
+        else:
+            assert torch.allclose(p.grad, gr[i], rtol=2e-4, atol=2e-6), i
+    want = [int(x) for x in ops.masked_correct(k["learned_out"], b.y, b.train_mask).tolist()]
+    assert cnt[0:2] == want
+
+
+def _kept(c, b):
+    """The slot's kept views cut to the staged partition's own sizes (slot buffers are capacity-sized)."""
+    E, N = b.edge_index.shape[1], b.x.shape[0]
+    k = {n: (None if t is None else t.clone()) for n, t in c.keep.items()}
+    k["edge_probs_full"] = k["edge_probs_full"][:E]
+    for n in ("learned_out", "random_out"):
+        if k[n] is not None:
+            k[n] = k[n][:N]
+    return k
 
 
 @pytest.mark.parametrize("pipeline", ["hybrid", "straight_through", "two_pass"])
 def test_sampled_replay_matches_eager_recomputation_from_its_own_draws(pipeline):
     import sgs_gnn_amd as S
     from sgs_gnn_amd.stepgraph import StepGraphs
-    from sgs_gnn_amd.training import _ce, learned_loss, SampledForward
-    ops = S.ops
     crit = torch.nn.CrossEntropyLoss()
     b = _batches(S, [4000])[0]
-    q, N = 800, b.x.shape[0]
+    q = 800
     m, og, oe = _setup(S, 0.0)
     a = _args(pipeline=pipeline)
-    sg = StepGraphs.attach(m, pipeline, a, crit, q, False)
+    sg = StepGraphs.attach(m, pipeline, a, crit, q, False, loader=[b])
+    sg.debug_keep = True
+    E = b.edge_index.shape[1]
     try:
-        sg.step(b, 0)                                  # eager warm-up visit
+        sg.step(b, 0)                                  # stage into a slot, warm up, capture, first replay
         for p in m.parameters():
             p.grad = None
-        sg.step(b, 0)                                  # capture + first replay
-        c = sg.table[next(iter(sg.table))]
-        params = list(m.parameters())
+        c = next(s_ for s_ in sg.slots[True] if s_.live is b)
+        assert c.ecap >= E and c.ecap % 2048 == 0 and int(c.dims.item()) == E
         seen = []
         for it in range(3):
             sg.replay_g1(c)
-            k = {n: (None if t is None else t.clone()) for n, t in c.keep.items()}
+            k = _kept(c, b)
             cnt = c.cbuf.tolist()
             seen.append(k["eid"].clone())
             c.g2l.replay()
@@ -90,58 +164,7 @@ def test_sampled_replay_matches_eager_recomputation_from_its_own_draws(pipeline)
             gr = {i: g.clone() for i, g in c.grads_r.items()}
             lr_ = c.loss_r.clone()
             torch.cuda.synchronize()
-            assert k["eid"].numel() == q and bool((k["eid"][1:] > k["eid"][:-1]).all())
-            assert torch.equal(k["sampled_edge_index"], b.edge_index[:, k["eid"]])
-
-            # eager recomputation from the replay's draws (epoch word irrelevant at dropout 0)
-            for p in params:
-                p.grad = None
-            sc = m.edge_prob_mlp
-            st = SampledForward()
-            st.rsei, st.sampled_edge_index = k["rsei"], k["sampled_edge_index"]
-            if pipeline == "two_pass":
-                with torch.no_grad():
-                    pf = sc(b.x, b.edge_index, k["rsei"]).squeeze()
-            else:
-                pf = sc(b.x, b.edge_index, k["rsei"]).squeeze()
-            assert torch.allclose(pf.detach(), k["edge_probs_full"], rtol=1e-5, atol=1e-6)
-            if pipeline == "hybrid":
-                act = getattr(sc, "last_active", None)
-                if act is not None:
-                    act.set(k["eid"], ops.get_graph(k["sampled_edge_index"], N))
-                w = pf.index_select(0, k["eid"])
-            elif pipeline == "two_pass":
-                w = sc(b.x, k["sampled_edge_index"]).squeeze()
-            else:
-                w = None
-            if w is not None:
-                st.edge_probs_for_loss = w
-                assert torch.allclose(w.detach(), k["w"], rtol=1e-5, atol=1e-6)
-                st.learned_out = m(b, k["sampled_edge_index"], w)
-                assert torch.allclose(st.learned_out.detach(), k["learned_out"], rtol=1e-4, atol=1e-5)
-                loss = learned_loss(a, crit, st, b)
-                loss.backward()
-                assert torch.allclose(loss.detach(), ll, rtol=1e-5, atol=1e-6)
-                for i, p in enumerate(params):
-                    if p.grad is None:
-                        assert i not in gl
-                    else:
-                        assert torch.allclose(p.grad, gl[i], rtol=2e-4, atol=2e-6), i
-            # random branch
-            for p in params:
-                p.grad = None
-            ro = m(b, k["rsei"])
-            assert torch.allclose(ro.detach(), k["random_out"], rtol=1e-4, atol=1e-5)
-            lr2 = _ce(crit, ro, b)
-            lr2.backward()
-            assert torch.allclose(lr2.detach(), lr_, rtol=1e-5, atol=1e-6)
-            for i, p in enumerate(params):
-                if p.grad is None:
-                    assert i not in gr
-                else:
-                    assert torch.allclose(p.grad, gr[i], rtol=2e-4, atol=2e-6), i
-            want = [int(x) for x in ops.masked_correct(k["learned_out"], b.y, b.train_mask).tolist()]
-            assert cnt[0:2] == want
+            _check_sampled_replay(S, m, a, crit, b, q, pipeline, k, cnt, gl, ll, gr, lr_)
         # every replay drew a different edge set; resetting the epoch word reproduces a replay exactly
         assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
         e = int(sg.epoch_word.item())
@@ -149,6 +172,64 @@ def test_sampled_replay_matches_eager_recomputation_from_its_own_draws(pipeline)
         sg.replay_g1(c)
         torch.cuda.synchronize()
         assert torch.equal(c.keep["eid"], seen[2])
+    finally:
+        sg.release()
+
+
+@pytest.mark.parametrize("pipeline", ["hybrid", "straight_through"])
+def test_one_capture_serves_partitions_of_different_sizes(pipeline):
+    """The step is captured ONCE per slot, over static buffers sized for the largest partition; a partition is handed over by one
+    staging launch and the kernels over the candidate edges read the live edge count from the slot.  Partitions with different
+    numbers of nodes (padded with isolated, unlabelled nodes) and edges -- visited in an order that leaves the leftovers of a
+    LARGER partition behind in the slot -- each reproduce their eager recomputation; nothing is captured after the first visits."""
+    import sgs_gnn_amd as S
+    from sgs_gnn_amd.stepgraph import StepGraphs
+    from sgs_gnn_amd.training import _ce
+    crit = torch.nn.CrossEntropyLoss()
+    shapes = [(150, 6100), (90, 2600), (120, 4000), (110, 900), (140, 1500), (100, 700)]
+    bs = [S.synthetic_graph(n, E, 24, 5, seed=40 + i, device=DEV) for i, (n, E) in enumerate(shapes)]
+    q = 1000
+    m, og, oe = _setup(S, 0.0)
+    a = _args(pipeline=pipeline)
+    sg = StepGraphs.attach(m, pipeline, a, crit, q, False, loader=bs)
+    sg.debug_keep = True
+    params = list(m.parameters())
+    try:
+        for rnd in range(2):
+            for b in bs:
+                E, N = b.edge_index.shape[1], b.x.shape[0]
+                h = sg.forward(b)
+                c = h.c
+                assert c.live is b and int(c.dims.item()) == E and c.npad == 150
+                if h.sampled:
+                    cnt = h.gate_counts()
+                    k = _kept(c, b)
+                    c.g2l.replay()
+                    gl = {i: g.clone() for i, g in c.grads_l.items()}
+                    ll = c.loss_l.clone()
+                    c.g2r.replay()
+                    gr = {i: g.clone() for i, g in c.grads_r.items()}
+                    lr_ = c.loss_r.clone()
+                    sg.host_epoch += 2
+                    torch.cuda.synchronize()
+                    _check_sampled_replay(S, m, a, crit, b, q, pipeline, k, cnt, gl, ll, gr, lr_)
+                else:
+                    loss = h.backward(None).clone()
+                    got = {i: g.clone() for i, g in c.grads.items()}
+                    torch.cuda.synchronize()
+                    for p in params:
+                        p.grad = None
+                    ref = _ce(crit, m(b, b.edge_index), b)
+                    ref.backward()
+                    assert torch.allclose(ref.detach(), loss, rtol=1e-5, atol=1e-6)
+                    for i, p in enumerate(params):
+                        if p.grad is None:
+                            assert i not in got
+                        else:
+                            assert torch.allclose(p.grad, got[i], rtol=2e-4, atol=2e-6), i
+                for p in params:
+                    p.grad = None
+        assert sg.captures == 4                        # two slots per kind, captured on their first use, nothing afterwards
     finally:
         sg.release()
 
@@ -214,7 +295,7 @@ def test_graph_mode_with_gat_model_straight_through():
     for n, p in m.named_parameters():
         assert torch.isfinite(p).all(), n
     assert any(not torch.equal(p, before[n]) for n, p in m.named_parameters() if "GAT" in n)
-    assert len(m._sgs_stepgraphs.table) == 3
+    assert m._sgs_stepgraphs.captures <= 4
 
 
 def test_prefix_prefetch_on_a_second_stream_changes_nothing(monkeypatch):
@@ -237,7 +318,7 @@ def test_prefix_prefetch_on_a_second_stream_changes_nothing(monkeypatch):
         a = _args(sgs_hipgraph=True)
         rets = [S.train(a, ep, 8, m, og, oe, None, crit, bs, q=q) for ep in range(8)]
         sg = m._sgs_stepgraphs
-        assert all(c.g0 is not None for c in sg.table.values() if c.sampled)
+        assert sg.slots[True] and all(c.g0 is not None for c in sg.slots[True])
         # the host's mirror of the epoch word (what a prefetched G0 is given) agrees with the device
         assert int(sg.epoch_word.item()) == sg.host_epoch
         results.append((rets, {n: p.detach().clone() for n, p in m.named_parameters()}))

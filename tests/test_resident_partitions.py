@@ -47,6 +47,28 @@ def test_resident_partitions_cpu_logic():
     assert sorted(a) == list(range(5))
 
 
+def test_partition_cache_round_trip(tmp_path):
+    """save() -> load(): the tensor-only safetensors cache (data.py: "on-disk partition cache") reproduces every resident batch bit for
+    bit, refuses a file with another partition count, and holds plain tensors + string metadata only."""
+    from safetensors import safe_open
+    S, b, part = _graph()
+    rp = S.ResidentPartitions(b.x, b.edge_index, b.y, b.train_mask, b.val_mask, b.test_mask, part, num_parts=5, device="cpu")
+    path = rp.save(str(tmp_path))
+    assert path.endswith("sgs_partitions_5.safetensors")
+    with safe_open(path, framework="pt") as f:
+        assert f.metadata()["format"] == "sgs-partitions-v1"
+        assert sorted(f.keys()) == sorted(["perm", "node_ptr", "edge_ptr", "x", "y", "train_mask", "val_mask", "test_mask", "edge_index", "prob"])
+    rl = S.ResidentPartitions.load(str(tmp_path), 5, device="cpu")
+    _check(S, b, part, rl, "cpu")
+    for a, c in zip(rp, rl):
+        for k in ("x", "edge_index", "y", "train_mask", "val_mask", "test_mask", "prob", "node_ids"):
+            assert torch.equal(getattr(a, k), getattr(c, k)), k
+        assert getattr(c, "edge_index").is_contiguous()
+    assert rl.dropped_edges == rp.dropped_edges
+    with pytest.raises((ValueError, FileNotFoundError)):
+        S.ResidentPartitions.load(str(tmp_path), 4, device="cpu")
+
+
 @pytest.mark.gpu
 def test_resident_partitions_on_device_and_train():
     S, b, part = _graph(n=400, e=12000, seed=4)
@@ -61,4 +83,4 @@ def test_resident_partitions_on_device_and_train():
     for ep in range(4):
         loss, _, cond, tot = S.train(args, ep, 4, m, og, oe, None, torch.nn.CrossEntropyLoss(), rp, q=300)
         assert tot == 5 and loss == loss
-    assert len(m._sgs_stepgraphs.table) == 5
+    assert 1 <= m._sgs_stepgraphs.captures <= 4                    # one capture per slot, whatever the number of partitions
