@@ -2,24 +2,35 @@
 """Headline benchmark: sampled edges/s + training steps/s of the SGS-GNN hybrid pipeline on a
 Reddit-like METIS-partition stream (20 % of edges kept), on N MI355X of one node.
 
-    python bench.py --gpus 1 --steps 60 --warmup 6
+    python bench.py --gpus 1 --steps 230 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one iteration of the reference's hot loop (training_hybrid.train's loop body:
 prior draw -> EdgeProbGCN scores for every edge -> learned draw -> weighted 2-layer GCN ->
 second GCN on the random subgraph -> F1 gate -> CE + reg1 + reg2 -> backward -> Adam steps) on
-one partition batch already resident in HBM.  Workload = SURVEY.md section 8d "S3": partitions of
-~1013 nodes, F=602, C=41, H=256, intra-partition edges in [60k, 500k] with 52 % above
-q = 100 000 (the reference run: 119 of 230 partitions, logs/pipeline_hybrid.log:8), dropout 0.3,
-conditional gate on, both regularisers on, fp32.  Data are synthetic (no network for Reddit).
+one partition batch already resident in HBM.  Workload = SURVEY.md section 8d "S3": the 230-partition
+stream of the reference's Reddit run (main.py:41-67: ClusterData / ClusterLoader(batch_size=1, shuffle=True)) --
+partitions of ~1013 nodes, F=602, C=41, H=256, intra-partition edges in [60k, 500k] with 52 % above
+q = 100 000 (119 of 230 partitions, logs/pipeline_hybrid.log:8), visited in a shuffled order, dropout 0.3,
+conditional gate on, both regularisers on, fp32.  Data are synthetic (no network for Reddit).  The timed region is
+K consecutive steps of that shuffled stream after W untimed ones; with one GPU the line also carries whole-epoch
+timings (`epochs`), per-branch step times (`branch_ms`) and the one-time capture cost (`capture_s`).
 
 Prints ONE JSON line (rank 0).  `value` = learned-sampled edges per second over all ranks
 (q per step whose partition has more than q edges; the prior-only draw is not counted).
+
+Other BASELINE.json configurations (one JSON line each, same metric, `config.workload` names them):
+    python bench.py --config S2      # CitationFull-Cora-like full graph (N=19 793, F=8 710, E=126 842, q=25 368)
+    python bench.py --config S4      # arxiv-year-like partitions, --GNN GAT, straight_through
 """
 import argparse
+import contextlib
+import io
 import json
 import os
+import random
+import statistics
 import sys
 import time
 
@@ -34,87 +45,135 @@ Q = 100_000
 N_NODES, NFEAT, NCLS, HID = 1013, 602, 41, 256
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (= vector peak)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E
 # forward variant 4 evaluates every fp32 product as SIX bf16 MFMA products over exact 3-way operand splits (fp32-faithful,
 # csrc/edge_score.hip): its matrix pipe is the bf16 one and it executes 6x the algorithmic flops, so the kernel's roofline
 # is the bf16 peak / 6 in algorithmic fp32 flops.
 BF16X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+METRIC = "sampled edges/sec + training steps/sec, Reddit hybrid 20% sparsity"
 
 
-def make_args(device):
-    return argparse.Namespace(
+def make_args(device, **kw):
+    a = argparse.Namespace(
         device=device, mode="learned", pipeline="hybrid", edge_mlp_type="GCN", conditional=True, sparse_edge_mlp=True,
         t_init=0.7, t_min=0.5, degree_bias_coef=0.3, reg1=True, reg2=True, regularizer1_coef=1.0, consist_reg_coef=0.5,
         hybrid_checkpoint=True, drop_rate=0.3, lr=1e-3)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
 
 
-def build_model(S, device, fused=True):
-    """Same two Adam optimisers over the same (overlapping) parameter sets as main.py:100,122; `fused` selects
+def build_model(S, device, fused=True, nfeat=NFEAT, hid=HID, ncls=NCLS, gnn="GCN"):
+    """Same two Adam optimisers over the same (overlapping) parameter sets as main.py:100-109,122; `fused` selects
     sgs_gnn_amd.FusedAdam (one launch per group, torch.optim.Adam's update rule and state layout, capturable) so that a
     replayed step includes its optimiser steps; 0 = torch.optim.Adam (foreach), stepped eagerly after each replay."""
     torch.manual_seed(42)
-    m = S.GNNModel(NFEAT, HID, NCLS, dropout_prob=0.3, edge_mlp_type="GCN").to(device)
+    if gnn == "GAT":
+        m = S.GATModel(nfeat, hid, ncls, dropout_prob=0.3, edge_mlp_type="GCN").to(device)
+    else:
+        m = S.GNNModel(nfeat, hid, ncls, dropout_prob=0.3, edge_mlp_type="GCN").to(device)
     Adam = S.FusedAdam if fused else torch.optim.Adam
-    opt_gnn = Adam([p for n, p in m.named_parameters() if "gcn" in n], lr=1e-3)             # main.py:100
-    opt_edge = Adam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-3)  # main.py:122
-    opt_all = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4)                               # main.py:123
+    opt_gnn = Adam([p for n, p in m.named_parameters() if "gcn" in n or "GAT" in n], lr=1e-3)      # main.py:100-109
+    opt_edge = Adam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-3)         # main.py:122
+    opt_all = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4)                          # main.py:123
     return m, opt_gnn, opt_edge, opt_all
 
 
-def kernel_roofline(S, model, batch, reps):
-    """Live HIP-event timing of the dominant kernel (the fused MFMA edge scorer, forward over all E
-    candidate edges of a partition) on the stream it is launched on (torch's current stream)."""
-    ops = S.ops
-    E = batch.edge_index.shape[1]
-    H = HID
-    sc = model.edge_prob_mlp
-    codes = torch.relu(torch.randn(N_NODES, H, device=batch.x.device))
-    L = S._lib.lib()
-    U = (codes @ sc.fc1.weight[:, H:].t()).contiguous()
-    out = torch.empty(E, dtype=torch.float32, device=codes.device)
-    ws = ops.workspace(L.sgs_edge_score_workspace_bytes(N_NODES, H, E), codes.device)
-    W1, b1, w2, b2 = sc.fc1.weight.detach().contiguous(), sc.fc1.bias.detach(), sc.fc2.weight.detach().reshape(-1).contiguous(), sc.fc2.bias.detach()
-
-    def launch():
-        S._lib.check(L.sgs_edge_score_fwd(codes.data_ptr(), U.data_ptr(), N_NODES, H, batch.edge_index.data_ptr(), E, 0, W1.data_ptr(),
-                                          b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), 0.3, 1, 2, out.data_ptr(), ws.data_ptr(),
-                                          ws.numel(), torch.cuda.current_stream().cuda_stream), "edge_score_fwd")
-    for _ in range(3):
-        launch()
+def _hip_time(fn, reps, warm=3):
+    """Average duration of fn() by HIP events on torch's current stream (the stream the ABI launches on)."""
+    for _ in range(warm):
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        launch()
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    return e0.elapsed_time(e1) / reps
+
+
+def _pmc_traffic(E):
+    """HBM bytes per launch of the scorer forward from the separate rocprofv3 --pmc passes on this very kernel and shape
+    (profiles/r0*_scorer_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction applied); None if the resident shape
+    differs from the profiled one."""
+    for name in ("r02_scorer_pmc.json", "r01_scorer_pmc.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if f"E={E}," in pmc["kernel"]:
+                return pmc["hbm_traffic_bytes_per_launch"]
+        except Exception:
+            pass
+    return None
+
+
+def kernel_roofline(S, model, batch, reps, n_nodes=N_NODES, hid=HID):
+    """Live HIP-event timing of the dominant kernel (the fused MFMA edge scorer, forward over all E
+    candidate edges of a partition) on the stream it is launched on (torch's current stream)."""
+    ops = S.ops
+    E = batch.edge_index.shape[1]
+    H = hid
+    sc = model.edge_prob_mlp
+    codes = torch.relu(torch.randn(n_nodes, H, device=batch.x.device))
+    L = S._lib.lib()
+    U = (codes @ sc.fc1.weight[:, H:].t()).contiguous()
+    out = torch.empty(E, dtype=torch.float32, device=codes.device)
+    ws = ops.workspace(L.sgs_edge_score_workspace_bytes(n_nodes, H, E), codes.device)
+    W1, b1, w2, b2 = sc.fc1.weight.detach().contiguous(), sc.fc1.bias.detach(), sc.fc2.weight.detach().reshape(-1).contiguous(), sc.fc2.bias.detach()
+
+    def launch():
+        S._lib.check(L.sgs_edge_score_fwd(codes.data_ptr(), U.data_ptr(), n_nodes, H, batch.edge_index.data_ptr(), E, 0, W1.data_ptr(),
+                                          b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), 0.3, 1, 2, out.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), torch.cuda.current_stream().cuda_stream), "edge_score_fwd")
+    ms = _hip_time(launch, reps)
     flops = E * (2.0 * H * H + 2.0 * H)          # algorithmic flops per launch after the W1 split (DESIGN.md)
     achieved = flops / (ms * 1e-3) / 1e12
-    # HBM bytes per launch come from the separate rocprofv3 --pmc passes on this very kernel and shape
-    # (profiles/r01_scorer_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction applied); null if the
-    # resident shape differs from the profiled one.
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_scorer_pmc.json")))
-        if f"E={E}," in pmc["kernel"]:
-            traffic = pmc["hbm_traffic_bytes_per_launch"]
-    except Exception:
-        pass
-    return {"bound": "mfma", "kernel": "edge_score_kernel<8,false,false> (sgs_edge_score_fwd)", "achieved": round(achieved, 3),
+    return {"bound": "mfma", "kernel": "sgs_edge_score_fwd", "achieved": round(achieved, 3),
             "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": traffic, "edges_per_launch": E, "ms_per_launch": round(ms, 4),
+            "traffic": _pmc_traffic(E), "edges_per_launch": E, "ms_per_launch": round(ms, 4),
             "flops_per_edge": 2 * H * H + 2 * H}
 
 
-def cpu_baseline(batch_cpu, steps=2):
+def scorer_roofline(S, model, big, score_variant, n_nodes=N_NODES, hid=HID, alts=True):
+    L = S._lib.lib()
+    names = {0: "lds_tiled", 1: "stream_32_edge_wave_tile", 2: "weight_stationary_persistent", 3: "stream_64_edge_wave_tile",
+             4: "bf16x6_split_on_bf16_mfma"}
+    auto = 4 if hid % 128 == 0 else 3
+    used = score_variant if score_variant >= 0 else auto           # automatic choice at this E (>= 65 536 edges)
+    alt = {}
+    if alts:
+        for v, name in names.items():                                  # in-process A/B of the scorer forward kernels
+            if v == used:
+                continue
+            L.sgs_edge_score_set_variant(v)
+            r_ = kernel_roofline(S, model, big, reps=20, n_nodes=n_nodes, hid=hid)
+            alt[name] = {"achieved": r_["achieved"], "ms_per_launch": r_["ms_per_launch"]}
+    L.sgs_edge_score_set_variant(score_variant)
+    roof = kernel_roofline(S, model, big, reps=20, n_nodes=n_nodes, hid=hid)       # the variant used by the timed steps
+    roof["kernel"] = f"sgs_edge_score_fwd, forward variant {used} ({names[used]})"
+    if used == 4:
+        roof["peak"] = round(BF16X6_PEAK_TFLOPS, 1)
+        roof["frac"] = round(roof["achieved"] / BF16X6_PEAK_TFLOPS, 4)
+        roof["peak_note"] = ("algorithmic fp32 flops; the kernel runs 6 bf16 MFMA products per fp32 product (exact 3-way splits, "
+                             "fp32-faithful), so peak = dense bf16 MFMA peak 2500 / 6")
+        roof["bf16_mfma_tflops_executed"] = round(6 * roof["achieved"], 1)
+        roof["vs_fp32_mfma_peak"] = round(roof["achieved"] / F32_MFMA_PEAK_TFLOPS, 4)
+    if alts:
+        roof["alt_variants"] = alt
+    return roof
+
+
+def cpu_baseline(batch_cpu, nfeat=NFEAT, hid=HID, ncls=NCLS, q=Q, warm=3, timed=10):
     """The oracle's hybrid step (the reference's op sequence on CPU: materialised [E,2H] scorer,
     torch topk draw, gather->mul->index_add GCN, losses, autograd, two Adam steps) on the host
-    cores, on a bounded sample of the same workload."""
+    cores, on a bounded sample of the same workload.  Protocol of BASELINE.md section 2: `warm` untimed
+    + `timed` timed steps, median."""
     from oracle import sgs_oracle as O
     threads = min(os.cpu_count(), 16)          # the GPU box's CPU share for one GPU
     torch.set_num_threads(threads)
-    P = {k: v.requires_grad_(True) for k, v in O.init_params(NFEAT, HID, NCLS, "GCN", seed=1).items()}
-    cfg = O.StepConfig(pipeline="hybrid", scorer="GCN", q=Q, conditional=True, drop_rate=0.3)
+    n = batch_cpu.x.shape[0]
+    P = {k: v.requires_grad_(True) for k, v in O.init_params(nfeat, hid, ncls, "GCN", seed=1).items()}
+    cfg = O.StepConfig(pipeline="hybrid", scorer="GCN", q=q, conditional=True, drop_rate=0.3)
     b = dict(x=batch_cpu.x, edge_index=batch_cpu.edge_index, y=batch_cpu.y, train_mask=batch_cpu.train_mask, prob=batch_cpu.prob)
     E = batch_cpu.edge_index.shape[1]
     g = torch.Generator().manual_seed(0)
@@ -122,9 +181,9 @@ def cpu_baseline(batch_cpu, steps=2):
 
     def one():
         nz = O.StepNoise(prior_noise=torch.empty(E).exponential_(1, generator=g), sample_noise=torch.empty(E).exponential_(1, generator=g))
-        nz.masks_pass1 = O.Masks(enc_hidden=torch.rand(N_NODES, HID, generator=g) > 0.3, score_hidden=torch.rand(E, HID, generator=g) > 0.3)
-        nz.gnn_keep_learned = torch.rand(N_NODES, HID, generator=g) > 0.3
-        nz.gnn_keep_random = torch.rand(N_NODES, HID, generator=g) > 0.3
+        nz.masks_pass1 = O.Masks(enc_hidden=torch.rand(n, hid, generator=g) > 0.3, score_hidden=torch.rand(E, hid, generator=g) > 0.3)
+        nz.gnn_keep_learned = torch.rand(n, hid, generator=g) > 0.3
+        nz.gnn_keep_random = torch.rand(n, hid, generator=g) > 0.3
         R = O.learned_step_forward(P, b, cfg, nz)
         for p_ in P.values():
             p_.grad = None
@@ -134,22 +193,25 @@ def cpu_baseline(batch_cpu, steps=2):
             if R["update_edge_mlp"]:
                 O.adam_step({k: v for k, v in P.items() if "edge_prob_mlp" in k}, grads, st_e)
             O.adam_step({k: v for k, v in P.items() if "gcn" in k}, grads, st_g)
-    one()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(warm):
         one()
-    dt = time.perf_counter() - t0
-    return {"value": round(Q * steps / dt, 1), "unit": "sampled edges/s", "steps_per_s": round(steps / dt, 4), "cores": threads,
-            "kind": "port", "sample": f"{steps} hybrid steps (after 1 warm-up) on one synthetic Reddit-like partition, "
-                                      f"n={N_NODES}, E={E}, q={Q}, F={NFEAT}, H={HID}, fp32, torch {torch.__version__} CPU"}
+    ts = []
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        one()
+        ts.append(time.perf_counter() - t0)
+    med = statistics.median(ts)
+    return {"value": round(q / med, 1), "unit": "sampled edges/s", "steps_per_s": round(1.0 / med, 4), "cores": threads,
+            "kind": "port", "sample": f"median of {timed} hybrid steps after {warm} warm-up steps (BASELINE.md protocol) on one synthetic "
+                                      f"partition, n={n}, E={E}, q={q}, F={nfeat}, H={hid}, fp32, torch {torch.__version__} CPU; "
+                                      f"min {min(ts):.3f} s, max {max(ts):.3f} s per step"}
 
 
 def pool_indices(sizes, rank, world, per_rank):
-    """Which partitions of the common stream rank `rank` holds, in step order.  Data-parallel steps end in a gradient all-reduce, so
-    a step lasts as long as its slowest rank: the stream is dealt out BY SIZE (sorted by edge count, rank r takes every world-th
-    one), so that the partitions the ranks process in the same step have adjacent sizes -- in particular all sampled or all
-    unsampled -- and the step order is then shuffled with a permutation common to all ranks."""
-    import random
+    """Which partitions of the common stream rank `rank` holds.  Data-parallel steps end in a gradient all-reduce, so a step lasts
+    as long as its slowest rank: the stream is dealt out BY SIZE (sorted by edge count, rank r takes every world-th one), so that
+    the partitions the ranks process in the same step have adjacent sizes -- in particular all sampled or all unsampled -- and the
+    step order is then shuffled with a permutation common to all ranks."""
     order = sorted(range(len(sizes)), key=lambda i: (sizes[i], i))
     mine = order[rank::world][:per_rank]
     perm = random.Random(1000).sample(range(len(mine)), len(mine))
@@ -166,18 +228,259 @@ def make_pool(S, rank, world, per_rank, device):
     return [parts[i] for i in idx]
 
 
+def _quiet_train(S, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return S.train(*a, **k)
+
+
+def _timed_train(S, world, *a, **k):
+    """barrier + synchronize on both sides; returns (seconds, train()'s return tuple)."""
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ret = _quiet_train(S, *a, **k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, ret
+
+
+def _reduce(world, device, dt, sampled):
+    t = torch.tensor([dt, float(sampled)], dtype=torch.float64, device=device)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        return float(tmax[0]), float(tsum[1])
+    return dt, float(sampled)
+
+
+# --------------------------------------------------------------------------------------------- S3 (headline)
+def run_s3(a, S, rank, world, device):
+    model, opt_gnn, opt_edge, opt_all = build_model(S, device, fused=bool(a.fused_adam))
+    crit = torch.nn.CrossEntropyLoss()
+    args = make_args(device)
+    t0 = time.perf_counter()
+    pool = make_pool(S, rank, world, a.parts, device)       # resident in HBM before any timing
+    torch.cuda.synchronize()
+    pool_s = time.perf_counter() - t0
+    P = len(pool)
+    order = random.Random(7).sample(range(P), P)             # ClusterLoader(shuffle=True): one permutation, common to all ranks
+    stream = lambda i: pool[order[i % P]]                    # noqa: E731
+    train_args = (model, opt_gnn, opt_edge, opt_all, crit)
+
+    capture_s, hbm0 = 0.0, torch.cuda.memory_allocated()
+    if a.hipgraph:
+        args.sgs_hipgraph = True
+        args.sgs_dp_global_gate = world > 1      # N > 1: one gate per step over the union of the ranks' batches (dist.py)
+        with contextlib.redirect_stdout(io.StringIO()):
+            capture_s = S.prepare_step_graphs(args, model, opt_gnn, opt_edge, crit, pool, q=Q)
+    graph_hbm = torch.cuda.memory_allocated() - hbm0
+
+    warm = [stream(i) for i in range(a.warmup)]
+    timed = [stream(a.warmup + i) for i in range(a.steps)]
+    sampled = sum(Q for b in timed if b.edge_index.shape[1] > Q)
+    if warm:
+        _quiet_train(S, args, 0, 10, *train_args, warm, q=Q, alternate_frequency=0)
+    dt, ret = _timed_train(S, world, args, 1, 10, *train_args, timed, q=Q, alternate_frequency=0)
+    dt_all, sampled_all = _reduce(world, device, dt, sampled)
+    n_above = sum(1 for b in timed if b.edge_index.shape[1] > Q)
+
+    rec = {
+        "metric": METRIC,
+        "value": round(sampled_all / dt_all, 1), "unit": "sampled edges/s",
+        "steps_per_s": round(a.steps * world / dt_all, 3),
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt_all / a.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "dtype_note": "fp32 tensors, accumulators and results throughout; the scorer's fp32 contractions (forward, and the backward's "
+                      "recompute / dv.W1a / tall weight-gradient GEMM) run as six bf16 MFMA products over exact 3-way operand splits "
+                      "(error measured at the fp32-MFMA kernels' level, see roofline.peak_note)",
+        "data": "synthetic",
+        "config": {"workload": f"Reddit-like METIS partition stream (S3): {P} partitions per GPU, shuffled, n=1013 F=602 C=41 H=256, E_b in "
+                               "[60k,500k] (52% above q), q=100000, hybrid pipeline, EdgeProbGCN scorer, conditional gate, reg1+reg2, "
+                               "dropout 0.3, Adam x2; partitions resident in HBM (no per-batch collation or H2D copy in the timed region, "
+                               "unlike training_hybrid.py:42)",
+                   "partitions": P, "partitions_above_q_in_window": n_above,
+                   "parallelism": f"dp{world} (partition-sharded by size across ranks, global gate, 1 flat gradient all-reduce/step)" if world > 1 else "single",
+                   "hipgraph_replay": bool(getattr(args, "sgs_hipgraph", False)),
+                   "adam": "sgs_gnn_amd.FusedAdam (in-graph)" if a.fused_adam else "torch.optim.Adam (foreach, eager)"},
+        "mean_loss": round(ret[0], 5), "conditional_updates": ret[2], "total_updates": ret[3],
+        "learned_fraction_in_window": round(ret[2] / max(n_above, 1), 3),
+        "capture_s": round(capture_s, 3), "graph_hbm_GiB": round(graph_hbm / 2**30, 3), "pool_build_s": round(pool_s, 2),
+    }
+    if world > 1:
+        rec["collective_backend"] = dist.get_backend()
+        rec["collective_ranks"] = dist.get_world_size()
+
+    if rank == 0 and world == 1:
+        # ---- whole epochs (the reference's timed region is a whole train() over all partitions, main.py:147-168)
+        epochs = []
+        for e in range(a.epochs):
+            eo = random.Random(100 + e).sample(range(P), P)
+            ep_batches = [pool[i] for i in eo]
+            dte, re_ = _timed_train(S, world, args, 2 + e, 10, *train_args, ep_batches, q=Q, alternate_frequency=0)
+            n_s = sum(1 for b in ep_batches if b.edge_index.shape[1] > Q)
+            epochs.append({"seconds": round(dte, 4), "steps_per_s": round(P / dte, 2), "sampled_edges_per_s": round(n_s * Q / dte, 1),
+                           "sampled_steps": n_s, "learned_steps": re_[2], "mean_loss": round(re_[0], 4)})
+        if epochs:
+            rec["epochs"] = epochs
+            rec["epoch1_incl_capture_s"] = round(capture_s + epochs[0]["seconds"], 4)
+        # ---- per-branch step times: one step per train() call with a device synchronisation around it (no look-ahead overlap)
+        if a.diag_steps > 0:
+            br = {"learned": [], "random": [], "unsampled": []}
+            for i in range(a.diag_steps):
+                b = stream(1000 + i)
+                dts, r_ = _timed_train(S, world, args, 5, 10, *train_args, [b], q=Q, alternate_frequency=0)
+                kind = "unsampled" if b.edge_index.shape[1] <= Q else ("learned" if r_[2] else "random")
+                br[kind].append(dts * 1e3)
+            rec["branch_ms"] = {k: (round(statistics.mean(v), 4) if v else None) for k, v in br.items()}
+            rec["branch_ms"]["n"] = {k: len(v) for k, v in br.items()}
+            rec["branch_ms"]["note"] = "one step per train() call, synchronised: includes the per-call host overhead, no prefetch overlap"
+        rec["hbm_reserved_GiB"] = round(torch.cuda.memory_reserved() / 2**30, 2)
+        big = max(pool, key=lambda b: b.edge_index.shape[1])
+        rec["roofline"] = scorer_roofline(S, model, big, a.score_variant)
+        if not a.no_cpu_baseline:
+            above = [b for b in pool if b.edge_index.shape[1] > Q]
+            cpu_b = min(above, key=lambda b: b.edge_index.shape[1]) if above else big      # smallest sampled partition: bounded CPU time
+            rec["cpu_baseline"] = cpu_baseline(cpu_b.to("cpu"))
+    elif rank == 0:
+        big = max(pool, key=lambda b: b.edge_index.shape[1])
+        rec["roofline"] = scorer_roofline(S, model, big, a.score_variant, alts=False)
+    return rec
+
+
+# --------------------------------------------------------------------------------------------- S2: CoraFull-like full graph
+def corafull_like(S, device, seed=5):
+    """CitationFull-Cora shapes (datasets.py:51-54; logs/log_macro.txt:37): N=19 793, F=8 710, 126 842 directed edges, 70 classes;
+    features: 0.7 % dense non-negative bag-of-words rows, L1-normalised; masks 0.2/0.4/0.4 (datasets.py:201)."""
+    N, F_, E, C = 19_793, 8_710, 126_842, 70
+    b = S.synthetic_graph(N, E, 8, C, seed=seed, train_frac=0.2, power=0.5, device=device)
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = (torch.rand(N, F_, device=device, generator=g) < 0.007).float() * torch.rand(N, F_, device=device, generator=g)
+    x[torch.arange(N, device=device), b.y * 100 % F_] += 0.5
+    b.x = x / x.sum(1, keepdim=True).clamp_min(1e-12)
+    return b
+
+
+def run_s2(a, S, device):
+    Fin, C = 8_710, 70
+    b = corafull_like(S, device)
+    E = b.edge_index.shape[1]
+    q = int(E * 0.2)                                        # main.py:54: un-partitioned graph
+    model, opt_gnn, opt_edge, opt_all = build_model(S, device, fused=bool(a.fused_adam), nfeat=Fin, ncls=C)
+    crit = torch.nn.CrossEntropyLoss()
+    args = make_args(device)
+    if a.hipgraph:
+        args.sgs_hipgraph = True
+    loader = [b]                                            # main.py:67: cluster_loader = [data]
+    cap = 0.0
+    if a.hipgraph:
+        with contextlib.redirect_stdout(io.StringIO()):
+            cap = S.prepare_step_graphs(args, model, opt_gnn, opt_edge, crit, loader, q=q)
+    for ep in range(a.warmup):
+        _quiet_train(S, args, ep, 10, model, opt_gnn, opt_edge, opt_all, crit, loader, q=q)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    learned = 0
+    for ep in range(a.steps):
+        r = _quiet_train(S, args, ep, 10, model, opt_gnn, opt_edge, opt_all, crit, loader, q=q)
+        learned += r[2]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # dominant kernel here: the node GEMM X W^T [N,F] x [F,H] (library GEMM through torch, hipBLASLt), run for the scorer's and the
+    # GNN's first layer every step
+    W = model.gcn1.lin.weight.detach()
+    ms = _hip_time(lambda: torch.mm(b.x, W.t()), 20)
+    flops = 2.0 * b.x.shape[0] * Fin * HID
+    ach = flops / (ms * 1e-3) / 1e12
+    rec = {"metric": METRIC, "value": round(q * a.steps / dt, 1), "unit": "sampled edges/s", "steps_per_s": round(a.steps / dt, 3), "n_gpus": 1,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"CitationFull-Cora-like full graph (S2): N={b.x.shape[0]} F={Fin} C={C} H={HID} E={E} q={q}, one batch per "
+                                  "epoch (main.py:67), hybrid pipeline, EdgeProbGCN scorer, conditional gate, reg1+reg2, dropout 0.3, Adam x2",
+                      "hipgraph_replay": bool(a.hipgraph)},
+           "conditional_updates": learned, "capture_s": round(cap, 3),
+           "roofline": {"bound": "mfma", "kernel": "node GEMM X W^T [19793 x 8710] x [8710 x 256] (hipBLASLt via torch.mm, fp32)",
+                        "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+                        "traffic": None, "ms_per_launch": round(ms, 4)}}
+    if not a.no_cpu_baseline:
+        rec["cpu_baseline"] = cpu_baseline(b.to("cpu"), nfeat=Fin, ncls=C, q=q, warm=1, timed=3)
+    return rec
+
+
+# --------------------------------------------------------------------------------------------- S4: arxiv-year-like, GAT, straight-through
+def run_s4(a, S, device):
+    Fin, C, n, Eb, parts = 128, 5, 33_869, 463_000, 5
+    q = Q                                                   # METIS-partitioned: q = threshold * sample_perc (main.py:50)
+    pool = [S.synthetic_graph(n, Eb, Fin, C, seed=300 + i, train_frac=0.2, power=0.6, device=device) for i in range(parts)]
+    model, opt_gnn, opt_edge, opt_all = build_model(S, device, fused=bool(a.fused_adam), nfeat=Fin, ncls=C, gnn="GAT")
+    crit = torch.nn.CrossEntropyLoss()
+    args = make_args(device, pipeline="straight_through")
+    cap = 0.0
+    if a.hipgraph:
+        args.sgs_hipgraph = True
+        with contextlib.redirect_stdout(io.StringIO()):
+            cap = S.prepare_step_graphs(args, model, opt_gnn, opt_edge, crit, pool, q=q)
+    for ep in range(max(a.warmup // parts, 1)):
+        _quiet_train(S, args, ep, 10, model, opt_gnn, opt_edge, opt_all, crit, pool, q=q)
+    epochs = max(a.steps // parts, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    learned = 0
+    for ep in range(epochs):
+        learned += _quiet_train(S, args, ep, 10, model, opt_gnn, opt_edge, opt_all, crit, pool, q=q)[2]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = epochs * parts
+    # K8 (GAT attention + aggregation over the drawn graph, nnz = q + n): bandwidth-bound gather; algorithmic bytes per SURVEY 8d
+    ops = S.ops
+    b0 = pool[0]
+    smp = ops.sample_topq(ops.SAMPLE_PRIOR, b0.prob, None, 0.0, q, b0.edge_index, seed=1, stream_id=1, want_p=False)
+    graph = ops.get_subgraph(b0.edge_index, n, smp)
+    xl = torch.randn(n, HID, device=device)
+    a_s, a_d = torch.randn(n, device=device), torch.randn(n, device=device)
+    bias = torch.zeros(HID, device=device)
+    with torch.no_grad():
+        ms = _hip_time(lambda: ops.gat_aggregate(xl, a_s, a_d, bias, graph, 0.2, 0.3, 7, 16, ops.ACT_RELU_DROPOUT, 0.3, 7, 32), 20)
+    nnz = q + n
+    alg = nnz * (4 + 4 + 4 * HID + 8) + 4 * HID * n + 8 * (n + 1)           # col + weight + gathered row + 2 node scalars per nnz; output; row pointers
+    rec = {"metric": METRIC, "value": round(q * steps / dt, 1), "unit": "sampled edges/s", "steps_per_s": round(steps / dt, 3), "n_gpus": 1,
+           "steps": steps, "warmup": a.warmup, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"arxiv-year-like partitions (S4): {parts} partitions, n={n} F={Fin} C={C} H={HID} E_b~{pool[0].edge_index.shape[1]} "
+                                  f"q={q}, --GNN GAT (heads 1), straight_through pipeline, EdgeProbGCN scorer, conditional gate, dropout 0.3, Adam x2",
+                      "hipgraph_replay": bool(a.hipgraph)},
+           "conditional_updates": learned, "capture_s": round(cap, 3),
+           "roofline": {"bound": "hbm", "kernel": "GAT layer forward over the drawn graph: sgs_gat_alpha_fwd + sgs_spmm_csr (D=256, nnz=q+n)",
+                        "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "ms_per_launch": round(ms, 4),
+                        "algorithmic_bytes": alg, "note": "gathered rows counted per nnz (uncached upper figure, SURVEY 8d); the 35 MB "
+                                                          "feature table is L2 / Infinity-Cache resident"}}
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--pool", type=int, default=12, help="distinct partition batches kept resident per rank")
+    ap.add_argument("--steps", type=int, default=230, help="timed steps (default: one epoch of the 230-partition stream)")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="S3", choices=["S3", "S2", "S4"])
+    ap.add_argument("--parts", type=int, default=230, help="S3: partitions of the stream kept resident per rank")
+    ap.add_argument("--epochs", type=int, default=2, help="S3, one GPU: additional whole-epoch timings")
+    ap.add_argument("--diag-steps", type=int, default=48, help="S3, one GPU: synchronised single steps for the per-branch times")
+    ap.add_argument("--pool", type=int, default=None, help="(deprecated alias of --parts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fused-adam", type=int, default=1, help="1 (default): sgs_gnn_amd.FusedAdam (one launch per group, captured with the step); 0: torch.optim.Adam (foreach, eager)")
     ap.add_argument("--score-variant", type=int, default=-1, help="scorer forward kernel for the timed steps (benchmarking A/B; -1 = library default)")
-    ap.add_argument("--hipgraph", type=int, default=1, help="1 (default): replay each partition's step from captured HIP graphs "
-                    "(stepgraph.py; every pool partition is visited twice -- eager, capture -- before the W warm-up steps); 0: eager launches")
+    ap.add_argument("--hipgraph", type=int, default=1, help="1 (default): every step replayed from the HIP graphs captured once over static "
+                    "slots (stepgraph.py); 0: eager launches")
     a = ap.parse_args()
+    if a.pool is not None:
+        a.parts = a.pool
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -205,94 +508,15 @@ def main():
     if a.score_variant >= 0:
         S._lib.lib().sgs_edge_score_set_variant(a.score_variant)
     S.fix_seeds(42 + rank)
-    model, opt_gnn, opt_edge, opt_all = build_model(S, device, fused=bool(a.fused_adam))
-    crit = torch.nn.CrossEntropyLoss()
-    args = make_args(device)
-
-    # partition pool (per rank: its own shard of the stream), resident in HBM before timing
-    pool = make_pool(S, rank, world, a.pool, device)
-    warm = [pool[i % len(pool)] for i in range(a.warmup)]
-    if a.hipgraph:
-        args.sgs_hipgraph = True
-        args.sgs_dp_global_gate = world > 1      # N > 1: one gate per step over the union of the ranks' batches (dist.py)
-        warm = list(pool) * 2 + warm
-    timed = [pool[i % len(pool)] for i in range(a.steps)]
-    sampled = sum(Q for b in timed if b.edge_index.shape[1] > Q)
-
-    import contextlib
-    import io
-    with contextlib.redirect_stdout(io.StringIO()):
-        if warm:
-            S.train(args, 0, 10, model, opt_gnn, opt_edge, opt_all, crit, warm, q=Q, alternate_frequency=0)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ret = S.train(args, 1, 10, model, opt_gnn, opt_edge, opt_all, crit, timed, q=Q, alternate_frequency=0)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-
-    t = torch.tensor([dt, float(sampled)], dtype=torch.float64, device=device)
-    if world > 1:
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_all, sampled_all = float(tmax[0]), float(tsum[1])
+    if a.config == "S3":
+        rec = run_s3(a, S, rank, world, device)
     else:
-        dt_all, sampled_all = dt, float(sampled)
-
+        if world > 1:
+            raise SystemExit("--config S2 / S4 are single-GPU lines")
+        if a.steps == 230:
+            a.steps = 20
+        rec = run_s2(a, S, device) if a.config == "S2" else run_s4(a, S, device)
     if rank == 0:
-        big = max(pool, key=lambda b: b.edge_index.shape[1])
-        L = S._lib.lib()
-        alts = {}
-        names = {0: "lds_tiled", 1: "stream_32_edge_wave_tile", 2: "weight_stationary_persistent", 3: "stream_64_edge_wave_tile",
-                 4: "bf16x6_split_on_bf16_mfma"}
-        used = a.score_variant if a.score_variant >= 0 else 4           # automatic choice at this E (>= 65 536 edges) and H = 256
-        for v, name in names.items():                                      # in-process A/B of the scorer forward kernels
-            if v == used:
-                continue
-            L.sgs_edge_score_set_variant(v)
-            r_ = kernel_roofline(S, model, big, reps=20)
-            alts[name] = {"achieved": r_["achieved"], "ms_per_launch": r_["ms_per_launch"]}
-        L.sgs_edge_score_set_variant(a.score_variant)
-        roof = kernel_roofline(S, model, big, reps=20)       # the variant used by the timed steps above
-        roof["kernel"] = f"sgs_edge_score_fwd, forward variant {used} ({names[used]})"
-        if used == 4:
-            roof["peak"] = round(BF16X6_PEAK_TFLOPS, 1)
-            roof["frac"] = round(roof["achieved"] / BF16X6_PEAK_TFLOPS, 4)
-            roof["peak_note"] = ("algorithmic fp32 flops; the kernel runs 6 bf16 MFMA products per fp32 product (exact 3-way splits, "
-                                 "fp32-faithful), so peak = dense bf16 MFMA peak 2500 / 6")
-            roof["bf16_mfma_tflops_executed"] = round(6 * roof["achieved"], 1)
-            roof["vs_fp32_mfma_peak"] = round(roof["achieved"] / F32_MFMA_PEAK_TFLOPS, 4)
-        roof["alt_variants"] = alts
-        rec = {
-            "metric": "sampled edges/sec + training steps/sec, Reddit hybrid 20% sparsity",
-            "value": round(sampled_all / dt_all, 1), "unit": "sampled edges/s",
-            "steps_per_s": round(a.steps * world / dt_all, 3),
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt_all / a.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "dtype_note": "fp32 tensors, accumulators and results throughout; the scorer's fp32 contractions (forward, and the backward's "
-                          "recompute / dv.W1a / tall weight-gradient GEMM) run as six bf16 MFMA products over exact 3-way operand splits "
-                          "(error measured at the fp32-MFMA kernels' level, see roofline.peak_note)",
-            "data": "synthetic",
-            "config": {"workload": "Reddit-like METIS partition stream (S3): n=1013 F=602 C=41 H=256, E_b in [60k,500k] "
-                                   "(52% above q), q=100000, hybrid pipeline, EdgeProbGCN scorer, conditional gate, reg1+reg2, "
-                                   "dropout 0.3, Adam x2", "pool": a.pool, "partitions_above_q": sum(1 for b in timed if b.edge_index.shape[1] > Q),
-                       "parallelism": f"dp{world} (partition-sharded by size across ranks, global gate, 1 flat gradient all-reduce/step)" if world > 1 else "single",
-                       "hipgraph_replay": bool(getattr(args, "sgs_hipgraph", False)),
-                       "adam": "sgs_gnn_amd.FusedAdam (in-graph)" if a.fused_adam else "torch.optim.Adam (foreach, eager)"},
-            "mean_loss": round(ret[0], 5), "conditional_updates": ret[2], "total_updates": ret[3],
-            "roofline": roof,
-        }
-        if not a.no_cpu_baseline and world == 1:
-            above = [b for b in pool if b.edge_index.shape[1] > Q]
-            cpu_b = min(above, key=lambda b: b.edge_index.shape[1]) if above else big      # smallest sampled partition: bounded CPU time
-            rec["cpu_baseline"] = cpu_baseline(cpu_b.to("cpu"))
         print(json.dumps(rec))
     if world > 1:
         dist.destroy_process_group()

@@ -6,7 +6,7 @@ from . import _lib, ops  # noqa: F401
 from .model import GCNConv, GNNModel, GATConv, GAT, GATModel, GINConv, GIN, GINModel, ChebConv, ChebModel, set_dropout_seed  # noqa: F401
 from .scorer import EdgeProbGCN, EdgeProbMLP, EdgeProbSAGE, SAGEConv, get_edge_mlp  # noqa: F401
 from .sampling import gumbel_softmax_sampling, random_edge_sampling, manual_seed  # noqa: F401
-from .training import train, train_hybrid, train_straight_through, train_two_pass  # noqa: F401
+from .training import train, train_hybrid, train_straight_through, train_two_pass, prepare_step_graphs  # noqa: F401
 from .evaluate import evaluate, ensemble_evaluate  # noqa: F401
 from .utils import calculate_f1, consistency_loss, fix_seeds  # noqa: F401
 from .optim import FusedAdam  # noqa: F401

@@ -250,6 +250,8 @@ class StepGraphs:
             E = int(b.edge_index.shape[1])
             n = max(n, int(b.x.shape[0]))
             e[E > self.q] = max(e[E > self.q], E)
+            if b.x.is_cuda and E > 0:
+                self._sources(b, want_norm=E <= self.q)      # CSR (+ unit normalisation) of every resident partition, once, up front
         self._set_capacity(n, e)
 
     def _set_capacity(self, n, e) -> None:
@@ -306,16 +308,20 @@ class StepGraphs:
         return s
 
     @staticmethod
-    def _sources(batch):
+    def _sources(batch, want_norm=False):
         """The partition's resident arrays the staging copy reads (built once per partition, cached on the batch): its tensors,
-        the CSR of its edge list and -- for the unsampled step -- the unit normalisation; the train mask as whole 4-byte words."""
+        the CSR of its edge list and -- for the unsampled step -- the unit normalisation; the train mask as whole 4-byte words.
+        Launches kernels that take scratch from the MAIN arena: call it on the main stream only (never on the prefetch stream,
+        where it would scribble over the scratch of the step in flight)."""
         src = getattr(batch, "_sgs_stage_src", None)
+        if src is not None and want_norm and src["norm"] is None:
+            src["norm"] = ops.gcn_norm(src["graph"], None)
         if src is None:
             N = int(batch.x.shape[0])
             g = ops.get_graph(batch.edge_index, N)
             m4 = torch.zeros(_round_up(N, 4), dtype=torch.uint8, device=batch.x.device)
             m4[:N] = ops._u8(batch.train_mask)
-            src = dict(graph=g, mask4=m4, x=batch.x.contiguous(), y=batch.y.contiguous(), norm=None)
+            src = dict(graph=g, mask4=m4, x=batch.x.contiguous(), y=batch.y.contiguous(), norm=ops.gcn_norm(g, None) if want_norm else None)
             try:
                 batch._sgs_stage_src = src
             except Exception:
@@ -327,7 +333,7 @@ class StepGraphs:
         hit = self.stage_cache.get(key)
         if hit is not None:
             return hit
-        src = self._sources(batch)
+        src = self._sources(batch, want_norm=not slot.sampled)
         g, sg = src["graph"], slot.graph
         N, E = int(batch.x.shape[0]), int(batch.edge_index.shape[1])
         Np, Ec = slot.npad, slot.ecap
@@ -351,8 +357,6 @@ class StepGraphs:
                      (ei.data_ptr() + E * 8, sb.edge_index.data_ptr() + Ec * 8, E * 8, E * 8, 0),
                      (batch.prob.contiguous(), sb.prob, E * 4, E * 4, 0)]
         else:
-            if src["norm"] is None:
-                src["norm"] = ops.gcn_norm(g, None)
             nm, sn = src["norm"], slot.norm
             segs += [(nm.what_in, sn.what_in, E * 4, E * 4, 0),
                      (nm.what_out, sn.what_out, E * 4, E * 4, 0),
@@ -374,7 +378,7 @@ class StepGraphs:
         arr, n, dims, _ = self._stage_desc(batch, slot)
         L = _lib.lib()
         _lib.check(L.sgs_stage_segments(arr, n, slot.dims.data_ptr(), dims, 1, ops._stream()), "sgs_stage_segments")
-        slot.live, slot.staged, slot.pre_epoch = batch, None, None
+        slot.live, slot.staged, slot.pre_epoch = batch, None, None      # (`live` also keeps the partition's tensors alive: its key stays unique)
 
     def _pick(self, sampled: bool, like, avoid=None) -> _Slot:
         sl = self.slots[sampled]
@@ -598,6 +602,12 @@ class StepGraphs:
         slot = self._pick(sampled, nxt, avoid=avoid)
         if slot.g1 is None:
             return                                     # not captured yet: the next forward() stages and captures in line
+        if (_batch_key(nxt), id(slot)) not in self.stage_cache:
+            # first hand-over of this partition: its CSR may still have to be built, with scratch from the main arena -> on the main
+            # stream, and the copy waits for it (once per partition; reserve() has done it for loaders it could scan)
+            self._stage_desc(nxt, slot)
+            after = torch.cuda.Event()
+            after.record(torch.cuda.current_stream())
         self.pre_stream.wait_event(after)
         with torch.cuda.stream(self.pre_stream):
             self._stage(nxt, slot)
@@ -630,12 +640,15 @@ class StepGraphs:
             main.wait_event(c.stage_event)
             prefix_ahead = c.g0 is not None and c.pre_epoch is not None and c.pre_epoch == self.host_epoch
         else:
-            c = self._pick(sampled, batch)
-            if self.last_pre is not None:
-                main.wait_event(self.last_pre)         # in line: after whatever the prefetch stream was last given
-            self._stage(batch, c)
-            if c.g1 is None:
-                self._capture(c)
+            # a partition that is still sitting in a slot (cluster_loader = [data], main.py:67: the same batch every step) is not copied again
+            c = next((s for s in self.slots[sampled] if s.live is not None and s.g1 is not None and _batch_key(s.live) == key), None)
+            if c is None:
+                c = self._pick(sampled, batch)
+                if self.last_pre is not None:
+                    main.wait_event(self.last_pre)     # in line: after whatever the prefetch stream was last given
+                self._stage(batch, c)
+                if c.g1 is None:
+                    self._capture(c)
         c.staged = None
         if c.g0 is not None and not prefix_ahead:
             if self.last_pre is not None:

@@ -154,6 +154,41 @@ def train(args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, opt
                   cluster_loader, q)
 
 
+def prepare_step_graphs(args, model, optimizer_gnn, optimizer_edge_prob, criterion, cluster_loader, q=500):
+    """Optional, `args.sgs_hipgraph` only: record the step's HIP graphs before the first epoch instead of inside it (train() does
+    it on demand otherwise).  The slots are sized for the largest partition of `cluster_loader`; a representative batch of each
+    kind (E_b > q, E_b <= q) is staged and the step is captured over both slots of that kind.  Nothing is trained: no optimiser
+    step runs (a capture records, it does not execute; the warm-up pass discards its gradients).  Returns the seconds spent."""
+    from .stepgraph import StepGraphs
+    pipeline = getattr(args, "pipeline", "two_pass")
+    if pipeline not in _PIPELINES:
+        pipeline = "two_pass"
+    sync = None
+    if is_parallel():
+        sync = getattr(model, "_sgs_gradsync", None)
+        if sync is None:
+            sync = model._sgs_gradsync = GradSync(model.parameters())
+    model.train()
+    sg = StepGraphs.attach(model, pipeline, args, criterion, q, bool(getattr(args, "hybrid_checkpoint", False)),
+                           optimizers=(optimizer_edge_prob, optimizer_gnn), sync=sync, loader=cluster_loader)
+    try:
+        before = sg.capture_seconds
+        batches = getattr(cluster_loader, "batches", cluster_loader)
+        for kind in (True, False):
+            rep = next((b for b in batches if (b.edge_index.shape[1] > q) == kind and _has_train_nodes(b)), None)
+            if rep is None:
+                continue
+            rep = rep.to(args.device)
+            for _ in range(2):
+                slot = sg._pick(kind, rep)
+                if slot.g1 is None:
+                    sg._stage(rep, slot)
+                    sg._capture(slot)
+        return sg.capture_seconds - before
+    finally:
+        sg.release()
+
+
 def train_hybrid(args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, optimizer, criterion, cluster_loader,
                  q=500, alternate_frequency=1):
     """training_hybrid.train (training_hybrid.py:7-8): same positional / keyword signature (`alternate_frequency` is dead there too)."""
