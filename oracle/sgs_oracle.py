@@ -86,16 +86,21 @@ def sampler_keys(edge_probs: torch.Tensor, prior: Optional[torch.Tensor], c: flo
 
 def gumbel_softmax_sampling(prior: Optional[torch.Tensor], edge_probs: torch.Tensor, q: int,
                             degree_bias_coef: float = 0.3, istest: bool = False,
-                            noise: Optional[torch.Tensor] = None, Z: Optional[torch.Tensor] = None):
+                            noise: Optional[torch.Tensor] = None, Z: Optional[torch.Tensor] = None,
+                            force_mask: Optional[torch.Tensor] = None):
     """sampling.py:91-155 with the multinomial's noise made explicit.
 
     Returns (mask [E] bool, weights [q] float in original edge order, clamped to [0,1],
     autograd-connected to edge_probs exactly as the reference: p * ((one_hot - s).detach() + s)).
+    `force_mask` (test hook): the draw's outcome given from outside instead of raced here.
     """
     samples, _ = sampler_keys(edge_probs, prior, degree_bias_coef, istest, Z)
-    _, sampled_edges = exp_race_topq(samples.detach(), noise, q)
     one_hot = torch.zeros_like(samples)
-    one_hot.scatter_(0, sampled_edges, 1.0)
+    if force_mask is not None:
+        one_hot[force_mask] = 1.0
+    else:
+        _, sampled_edges = exp_race_topq(samples.detach(), noise, q)
+        one_hot.scatter_(0, sampled_edges, 1.0)
     straight_through = (one_hot - samples).detach() + samples
     weighted = edge_probs * straight_through
     indexs = one_hot.bool()
@@ -346,20 +351,35 @@ class StepNoise:
     gnn_keep_random: Optional[torch.Tensor] = None
 
 
+def gat_forward(P, x, edge_index, edge_weight=None, p=0.0, keep=None, prefix="GAT.convs."):
+    """GATModel.forward (model.py:201-208 -> PyG GAT(num_layers=2, heads=1, act=relu)); `edge_weight` is dropped as PyG's
+    BasicGNN does for a conv without edge-weight support; attention dropout is not restated here (p must be 0)."""
+    assert p == 0.0 and keep is None
+    h = F.relu(gat_conv(x, edge_index, P[prefix + "0.lin_src.weight"], P[prefix + "0.att_src"].reshape(-1),
+                        P[prefix + "0.att_dst"].reshape(-1), P[prefix + "0.bias"]))
+    return gat_conv(h, edge_index, P[prefix + "1.lin_src.weight"], P[prefix + "1.att_src"].reshape(-1),
+                    P[prefix + "1.att_dst"].reshape(-1), P[prefix + "1.bias"])
+
+
 def learned_step_forward(P: Dict[str, torch.Tensor], batch, cfg: StepConfig, noise: StepNoise,
-                         force_gate: Optional[bool] = None):
+                         force_gate: Optional[bool] = None, force_random_idx: Optional[torch.Tensor] = None,
+                         force_mask: Optional[torch.Tensor] = None, gnn=None):
     """One `mode == 'learned'`, `E > q` step up to (and including) the loss, for the three
     pipelines: training_hybrid.py:41-141, training_straight_through.py:38-130,
     training_two_pass.py:38-135.  `P` maps the reference's state_dict keys to leaf tensors
-    (requires_grad as the caller wishes).  Returns a dict of every intermediate."""
+    (requires_grad as the caller wishes).  Returns a dict of every intermediate.
+    Test hooks for parity at sizes where one last-ulp difference in a key could flip a near-tie of the exponential race:
+    `force_random_idx` / `force_mask` replace the two draws' outcomes (the draws themselves are then compared separately);
+    `gnn` replaces GNNModel.forward (e.g. `gat_forward` for --GNN GAT)."""
     x, ei, y, tm, prior = batch["x"], batch["edge_index"], batch["y"], batch["train_mask"], batch["prob"]
     q, p = cfg.q, cfg.drop_rate
     scorer = edge_prob_gcn if cfg.scorer == "GCN" else edge_prob_mlp
+    gnn_forward_ = gnn if gnn is not None else gnn_forward
     R: Dict[str, object] = {}
 
     rsei = None
     if cfg.conditional or cfg.sparse_edge_mlp:
-        ridx = prior_draw(prior, noise.prior_noise, q)
+        ridx = force_random_idx if force_random_idx is not None else prior_draw(prior, noise.prior_noise, q)
         rsei = ei[:, ridx]
         R["random_idx"] = ridx
         R["rsei"] = rsei
@@ -373,7 +393,7 @@ def learned_step_forward(P: Dict[str, torch.Tensor], batch, cfg: StepConfig, noi
         probs_in = probs_full.detach() if cfg.pipeline == "hybrid" else probs_full
     R["edge_probs_full"] = probs_full
 
-    mask, st_w = gumbel_softmax_sampling(prior, probs_in, q, cfg.degree_bias_coef, False, noise.sample_noise)
+    mask, st_w = gumbel_softmax_sampling(prior, probs_in, q, cfg.degree_bias_coef, False, noise.sample_noise, force_mask=force_mask)
     sei = ei[:, mask]
     R["mask"], R["sei"] = mask, sei
 
@@ -385,13 +405,13 @@ def learned_step_forward(P: Dict[str, torch.Tensor], batch, cfg: StepConfig, noi
         w = scorer(P, x, sei, None, p, noise.masks_pass3).squeeze()
     R["w"] = w
 
-    learned_out = gnn_forward(P, x, sei, w, p, noise.gnn_keep_learned)
+    learned_out = gnn_forward_(P, x, sei, w, p, noise.gnn_keep_learned)
     R["learned_out"] = learned_out
 
     update_edge_mlp = True
     random_out = None
     if cfg.conditional:
-        random_out = gnn_forward(P, x, rsei, None, p, noise.gnn_keep_random)
+        random_out = gnn_forward_(P, x, rsei, None, p, noise.gnn_keep_random)
         R["random_out"] = random_out
         lc, rc = correct_count(learned_out, y, tm), correct_count(random_out, y, tm)
         R["learned_correct"], R["random_correct"] = lc, rc

@@ -16,12 +16,18 @@ take the same branch and no rank waits through another's learned backward.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def is_parallel() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """A process group with more than one rank -- or, with SGS_DP_FORCE=1, any initialised group: lets a ONE-GPU box drive the
+    whole data-parallel path (bucket all-reduce between graph replays, gate sum, shared optimiser graph) through RCCL itself."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("SGS_DP_FORCE") == "1"
 
 
 def shard_batches(batches, rank: int, world: int):

@@ -33,6 +33,13 @@ def _world():
     return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
 
 
+def _comm() -> bool:
+    """Are the collectives issued?  More than one rank -- or SGS_DP_FORCE=1 with an initialised group, which lets a one-GPU box run
+    every collective of the sharded step through RCCL (world size 1)."""
+    from .dist import is_parallel
+    return is_parallel()
+
+
 def shard_bounds(E_total: int, world: int, chunk: int = 2048):
     """Contiguous edge ranges, boundaries at multiples of `chunk` (the sampler's reduction granule)."""
     nchunks = (E_total + chunk - 1) // chunk
@@ -60,7 +67,7 @@ class EdgeShard:
 def _all_gather_concat(t: torch.Tensor, sizes):
     """All-gather 1-D tensors of per-rank lengths `sizes` and concatenate them in rank order."""
     rank, world = _world()
-    if world == 1:
+    if not _comm():
         return t
     m = max(max(sizes), 1)
     buf = torch.zeros(m, dtype=t.dtype, device=t.device)
@@ -113,12 +120,12 @@ def dist_sample_topq(mode: int, p_local, prior_local, c: float, q: int, edge_ind
     for ps in range(3):
         if ps > 0:
             _lib.check(L.sgs_sampler_shard_hist(ws.data_ptr(), E, ps, ops._ptr(state), ops._ptr(hist), st), "shard_hist")
-        if world > 1:
+        if _comm():
             dist.all_reduce(hist)                                      # integer counts: exact
         _lib.check(L.sgs_sampler_select(ops._ptr(hist), ps, q, ops._ptr(state), st), "sampler_select")   # zeroes hist
     counts = torch.zeros(2, dtype=torch.int32, device=dev)
     _lib.check(L.sgs_sampler_shard_count(ws.data_ptr(), E, ops._ptr(state), ops._ptr(counts), ws.data_ptr(), ws.numel(), st), "shard_count")
-    if world > 1:
+    if _comm():
         allc = [torch.empty_like(counts) for _ in range(world)]
         dist.all_gather(allc, counts)
         allc = torch.stack(allc).tolist()
@@ -153,7 +160,7 @@ def sharded_norm(graph: ops.Graph, w):
     deg = torch.empty(graph.N, **f32)
     _lib.check(L.sgs_gcn_degree_partial(ops._ptr(w), graph.n_edges, graph.N, ops._ptr(graph.in_ptr), ops._ptr(graph.in_src),
                                         ops._ptr(graph.in_eid), ops._ptr(deg), ops._stream()), "sgs_gcn_degree_partial")
-    if world > 1:
+    if _comm():
         dist.all_reduce(deg)
     nm = ops.Norm()
     nm.graph, nm.w, nm.handle = graph, w, None
@@ -176,7 +183,7 @@ def sharded_propagate(xl, nm, bias, act=ops.ACT_NONE, p=0.0, seed=0, site=0):
     N, D = xl.shape
     part = ops._spmm(xl.contiguous(), gr.in_ptr, gr.in_src, nm.what_in, nm.what_loop if rank == 0 else None, None, ops.ACT_NONE, 0.0,
                      0, 0, N, D, gr.n_edges)
-    if world > 1:
+    if _comm():
         dist.all_reduce(part)
     Y = torch.empty_like(part)
     _lib.check(L.sgs_bias_act(ops._ptr(part), ops._ptr(bias), N, D, act, float(p), seed, site, ops._ptr(Y), ops._stream()), "sgs_bias_act")
@@ -221,7 +228,7 @@ class _F(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
-        if _world()[1] > 1:
+        if _comm():
             g = g.clone()
             dist.all_reduce(g)
         return g
@@ -231,7 +238,7 @@ class _G(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         y = x.clone()
-        if _world()[1] > 1:
+        if _comm():
             dist.all_reduce(y)
         return y
 
@@ -293,7 +300,7 @@ class _ShardedNorm(torch.autograd.Function):
         _lib.check(L.sgs_gcn_norm_bwd_node(ops._ptr(wv), ops._ptr(gw), ops._ptr(gl), n, N, ops._ptr(nm.dis), ops._ptr(nm.loopw),
                                            ops._ptr(gr.in_ptr), ops._ptr(gr.in_src), ops._ptr(gr.in_eid), ops._ptr(gr.out_ptr),
                                            ops._ptr(gr.out_dst), ops._ptr(gr.out_eid), ops._ptr(Hn), ops._stream()), "sgs_gcn_norm_bwd_node")
-        if world > 1:
+        if _comm():
             dist.all_reduce(Hn)
         dw = torch.empty(n, dtype=torch.float32, device=g.device)
         if n > 0:
@@ -336,7 +343,7 @@ class _ShardedEdgeReg(torch.autograd.Function):
         ws = ops.workspace(L.sgs_edge_reg_workspace_bytes(q), dev)
         _lib.check(L.sgs_edge_reg_partial(ops._ptr(w), ops._ptr(sei), q, ops._ptr(logits), N, C, ops._ptr(y), ops._ptr(mask_u8),
                                           ops._ptr(raw), ws.data_ptr(), ws.numel(), ops._stream()), "sgs_edge_reg_partial")
-        if _world()[1] > 1:
+        if _comm():
             dist.all_reduce(raw)
         reg1 = torch.where(raw[3] > 1.0, raw[0] / raw[2], torch.zeros((), device=dev))          # training_hybrid.py:125-128
         reg2 = raw[1] / float(q_global)

@@ -315,3 +315,72 @@ def test_sharded_training_step_matches_single_gpu_train():
                 torch.testing.assert_close(torch.from_numpy(o["params"][k]), v, rtol=0, atol=2.5e-3)
             for k in o["params"]:                                     # replicas are bit-identical to each other
                 assert (o["params"][k] == got[0]["params"][k]).all(), (world, k)
+
+
+def _rccl_worker(port, q_out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", SGS_DP_FORCE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        import contextlib
+        import io
+        from importlib import import_module
+        import sgs_gnn_amd as S
+        D = import_module("sgs_gnn_amd.dist")
+        assert D.is_parallel() and dist.get_backend() == "nccl"
+        out = {}
+        # (i) graph-mode data parallel: bucket all-reduce between replays, gate sum, shared optimiser graph -- through RCCL
+        S.fix_seeds(100)
+        torch.manual_seed(0)
+        m = S.GNNModel(12, 32, 5, dropout_prob=0.3, edge_mlp_type="GCN").to(DEV)
+        og = S.FusedAdam([p for n, p in m.named_parameters() if "gcn" in n], lr=1e-2)
+        oe = S.FusedAdam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-2)
+        batches = [S.synthetic_graph(300, e, 12, 5, seed=i, train_frac=0.5, device=DEV) for i, e in enumerate([6000, 900, 5000, 7000])]
+        args = argparse.Namespace(device=DEV, mode="learned", pipeline="hybrid", conditional=True, sparse_edge_mlp=True, t_init=0.7,
+                                  t_min=0.5, degree_bias_coef=0.3, reg1=True, reg2=True, regularizer1_coef=1.0,
+                                  consist_reg_coef=0.5, hybrid_checkpoint=False, sgs_hipgraph=True, sgs_dp_global_gate=True)
+        with contextlib.redirect_stdout(io.StringIO()):
+            for ep in range(4):
+                ret = S.train(args, ep, 4, m, og, oe, None, torch.nn.CrossEntropyLoss(), batches, q=1000)
+        sg = m._sgs_stepgraphs
+        out["dp"] = dict(ret=ret, dp=bool(sg.dp), g3=sg.g3 is not None,
+                         finite=all(bool(torch.isfinite(p).all()) for p in m.parameters()),
+                         state={k: v.detach().cpu().numpy() for k, v in m.state_dict().items()})
+        # (ii) the edge-sharded training step (config 5) with every collective issued (world size 1)
+        sh = import_module("sgs_gnn_amd.sharded")
+        S2, b, m2, og2, oe2, args2 = _train_setup()
+        shard = sh.EdgeShard(b, 0, 1)
+        S.fix_seeds(5)
+        tr = sh.train_step_sharded(args2, m2, shard, og2, oe2, torch.nn.CrossEntropyLoss(), b.edge_index.shape[1] // 5)
+        out["sharded"] = dict(loss=float(tr["loss"]), mask=tr["sample"].mask.cpu().numpy(), logits=tr["learned_out"].cpu().numpy())
+        q_out.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_runs_the_data_parallel_and_the_sharded_step():
+    """backend "nccl" (= RCCL on ROCm), world size 1, SGS_DP_FORCE=1: RCCL communicator initialisation on this box, device-tensor
+    all-reduces on RCCL's stream between HIP-graph replays (captures in thread-local mode beside the watchdog thread), the gate
+    sum, the shared optimiser graph and every collective of the edge-sharded step.  With one rank every collective is the
+    identity, so the results must equal the plain single-process runs."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=300)
+    p.join(120)
+    assert p.exitcode == 0
+    assert out["dp"]["dp"] and out["dp"]["g3"] and out["dp"]["finite"] and out["dp"]["ret"][3] == 4
+    # the sharded step against the regular single-GPU train() (same seeds: noise and dropout are keyed by global edge id)
+    S, b, m, og, oe, args = _train_setup()
+    S.fix_seeds(5)
+    args._sgs_trace = tr = {}
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        S.train(args, 0, 10, m, og, oe, None, torch.nn.CrossEntropyLoss(), [b], q=b.edge_index.shape[1] // 5)
+    assert torch.equal(torch.from_numpy(out["sharded"]["mask"]), tr["sample"].mask.cpu())
+    torch.testing.assert_close(torch.from_numpy(out["sharded"]["logits"]), tr["learned_out"].cpu(), rtol=1e-4, atol=1e-5)

@@ -14,6 +14,8 @@ segs.append(cur)
 names = ["G0 (parameter-independent prefix: prior draw, CSR of the random graph, unit norm) big",
          "G1 (scores, learned draw, encoders, gate counts) big", "G2R (random backward + Adam) big",
          "G2L (learned backward + 2 Adam) big", "G (unsampled step) small"]
+skip = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # trailing segments that are not traced replays (g1_trace.py's HIP-event loop)
+segs = segs[:len(segs) - skip] if skip else segs
 if len(segs) < 3 * len(names):       # capture without a prefix graph: no G0 segment
     names = names[1:]
 segs = segs[-3 * len(names):]
