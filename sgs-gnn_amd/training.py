@@ -49,7 +49,7 @@ def _has_train_nodes(batch) -> bool:
 
 class SampledForward:
     """Everything the sampled step's forward leaves behind for the gate and the two possible backwards."""
-    __slots__ = ("rsei", "edge_probs_full", "smp", "sampled_edge_index", "edge_probs_for_loss", "learned_out",
+    __slots__ = ("rsei", "rs", "edge_probs_full", "smp", "sampled_edge_index", "edge_probs_for_loss", "learned_out",
                  "random_out", "cbuf")
 
 
@@ -80,10 +80,10 @@ def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise
     N = batch.x.shape[0]
     scorer = model.edge_prob_mlp
 
-    st.rsei = None
+    st.rsei, st.rs = None, None
     if args.conditional or args.sparse_edge_mlp:                      # K0: prior-only draw (`prefix`: already made by sampled_prefix)
         rs = prefix if prefix is not None else sampled_prefix(args, batch, q, noise)
-        st.rsei = rs.edge_index
+        st.rsei, st.rs = rs.edge_index, rs
     st.random_out = None
     forked = side_stream is not None and args.conditional and st.rsei is not None
     if forked:
@@ -380,7 +380,7 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
                         optimizer_gnn.step()
 
                 if trace is not None:
-                    trace.update(rsei=st.rsei, edge_probs_full=st.edge_probs_full.detach(), sample=st.smp,
+                    trace.update(rsei=st.rsei, prior_sample=st.rs, edge_probs_full=st.edge_probs_full.detach(), sample=st.smp,
                                  w=st.edge_probs_for_loss.detach(), learned_out=st.learned_out.detach(),
                                  random_out=None if st.random_out is None else st.random_out.detach(), counts=counts,
                                  update_edge_mlp=update_edge_mlp, loss=loss.detach())
