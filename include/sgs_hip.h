@@ -432,6 +432,11 @@ void sgs_gemm_tn_set_tall_variant(int variant);   /* tall-K shapes (K >= 8192): 
 int sgs_gemm_tn_can_colsum(int64_t K, int64_t M, int64_t N);
 int sgs_gemm_tn_colsum(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, float* colsum_A, void* ws,
                        size_t ws_bytes, sgs_stream_t stream);
+/* The same product written with row stride ldc >= N, i.e. into a column block of a wider matrix: the two halves of d fc1.weight
+ * [H, 2H] (model.py:29-31: W1 [x*y | x-y]) are d W1a = dv^T feat and d W1b = dU^T codes, each an [H, H] block with ldc = 2H.
+ * colsum_A may be NULL (otherwise as sgs_gemm_tn_colsum).  Workspace: sgs_gemm_tn_workspace_bytes(K, M, N). */
+int sgs_gemm_tn_ld(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, int64_t ldc, float* colsum_A, void* ws,
+                   size_t ws_bytes, sgs_stream_t stream);
 
 /* ----------------------------------------------------------------------------------
  * Effective-resistance edge prior (datasets.py:159-173 add_ER; estimator: EffectiveResistanceWeights.ipynb cell 11 er_edge).

@@ -11,6 +11,12 @@
 #include "sgs_common.h"
 
 namespace sgs {
+size_t graph_sort_workspace_bytes(int64_t n, int64_t N);
+int graph_build_by_sort(const int64_t* ei, int64_t n, int64_t N, int32_t* in_ptr, int32_t* in_src, int32_t* in_eid, int32_t* out_ptr,
+                        int32_t* out_dst, int32_t* out_eid, int32_t* loop_eid, void* ws, size_t ws_bytes, hipStream_t stream);
+}
+
+namespace sgs {
 namespace {
 
 constexpr int kT = 256;
@@ -790,9 +796,13 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 extern "C" {
 
+// large edge lists: two stable radix sorts instead of atomics + per-row sorts (csrc/graph_sort.hip)
+constexpr int64_t kSortEdges = int64_t(1) << 22;
+
 size_t sgs_graph_build_workspace_bytes(int64_t n_edges, int64_t N) {
     if (n_edges < 0) n_edges = 0;
     if (N < 0) N = 0;
+    if (n_edges >= kSortEdges) return graph_sort_workspace_bytes(n_edges, N);
     return 4 * carve_bytes(N + 1, 4) + 2 * carve_bytes(n_edges + 1, 4) + 512;
 }
 
@@ -807,6 +817,8 @@ int sgs_graph_build(const int64_t* edge_index, int64_t n_edges, int64_t N, int32
                 SGS_EINVAL, "sgs_graph_build: null pointer");
     SGS_REQUIRE(ws && ws_bytes >= sgs_graph_build_workspace_bytes(n_edges, N), SGS_EWORKSPACE,
                 "sgs_graph_build: workspace too small");
+    if (n_edges >= kSortEdges)
+        return graph_build_by_sort(edge_index, n_edges, N, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, loop_eid, ws, ws_bytes, stream);
     Carver cv(ws);
     int* cnt_in = cv.take<int>(N + 1);
     int* cnt_out = cv.take<int>(N + 1);

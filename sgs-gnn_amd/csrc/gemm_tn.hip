@@ -52,8 +52,10 @@ __global__ void __launch_bounds__(64) gemm_tn_tile(const float* __restrict__ A, 
     }
 }
 
+// `N`, `ldc`: C is written with row stride ldc (>= N): the result may be a column block of a wider matrix (fc1.weight's halves)
 __global__ void __launch_bounds__(256) gemm_tn_reduce(const float* __restrict__ slab, int64_t mn, int ksplit, float* __restrict__ C,
-                                                      const float* __restrict__ cpart = nullptr, int M = 0, float* __restrict__ colsum = nullptr) {
+                                                      const float* __restrict__ cpart = nullptr, int M = 0, float* __restrict__ colsum = nullptr,
+                                                      int N = 0, int64_t ldc = 0) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (i >= mn) {
         const int64_t c = i - mn;                       // trailing threads: the column sums of A, slices in the same fixed order
@@ -66,7 +68,8 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce(const float* __restrict__ 
     }
     float acc = 0.f;
     for (int s = 0; s < ksplit; ++s) acc += slab[static_cast<int64_t>(s) * mn + i];
-    C[i] = acc;
+    if (ldc > 0 && ldc != N) C[(i / N) * ldc + (i % N)] = acc;
+    else C[i] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -283,7 +286,7 @@ size_t sgs_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N) {
 }
 
 static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, float* colsum_A, void* ws,
-                        size_t ws_bytes, hipStream_t stream);
+                        size_t ws_bytes, hipStream_t stream, int64_t ldc = 0);
 // tall-K shapes: 1 = bf16x6 kernel (default; measured 147 vs 175 us incl. the 34 us slab reduction at K = 100 000, M = N = 256: the
 // operand splits, 264 vector instructions per 48 MFMAs, are at the budget the matrix pipe leaves), 0 = fp32-MFMA kernel
 static int g_tall_bf16x6 = 1;
@@ -303,8 +306,15 @@ int sgs_gemm_tn_colsum(const float* A, const float* B, int64_t K, int64_t M, int
     return gemm_tn_impl(A, B, K, M, N, C, colsum_A, ws, ws_bytes, static_cast<hipStream_t>(stream_));
 }
 
+int sgs_gemm_tn_ld(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, int64_t ldc, float* colsum_A, void* ws,
+                   size_t ws_bytes, sgs_stream_t stream_) {
+    SGS_REQUIRE(ldc >= N, SGS_EINVAL, "sgs_gemm_tn_ld: ldc < N");
+    SGS_REQUIRE(!colsum_A || sgs_gemm_tn_can_colsum(K, M, N), SGS_EINVAL, "sgs_gemm_tn_ld: column sums only for the tall-K shapes");
+    return gemm_tn_impl(A, B, K, M, N, C, colsum_A, ws, ws_bytes, static_cast<hipStream_t>(stream_), ldc);
+}
+
 static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, float* colsum_A, void* ws,
-                        size_t ws_bytes, hipStream_t stream) {
+                        size_t ws_bytes, hipStream_t stream, int64_t ldc) {
     SGS_REQUIRE(K >= 0 && M >= 0 && N >= 0 && M < (1 << 30) && N < (1 << 30), SGS_EINVAL, "sgs_gemm_tn: bad sizes");
     if (M == 0 || N == 0) return SGS_OK;
     SGS_REQUIRE(C && (K == 0 || (A && B)), SGS_EINVAL, "sgs_gemm_tn: null pointer");
@@ -313,7 +323,8 @@ static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, in
     Carver cv(ws);
     float* slab = cv.take<float>(static_cast<size_t>(ks) * M * N);
     float* cpart = cv.take<float>(static_cast<size_t>(ks) * M);
-    float* dst = ks == 1 ? C : slab;
+    const bool strided = ldc > 0 && ldc != N;                  // the tile kernels write dense [M, N]: a strided C goes through the reduce
+    float* dst = (ks == 1 && !strided) ? C : slab;
     if (use_tall(K, M, N) && g_tall_bf16x6)
         hipLaunchKernelGGL(gemm_tn_tall_bf16x6, dim3(cdiv(M, 128), cdiv(N, 64), ks), dim3(64), 0, stream, A, B, K, static_cast<int>(M),
                            static_cast<int>(N), ks, dst, colsum_A ? cpart : static_cast<float*>(nullptr));
@@ -323,9 +334,9 @@ static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, in
     else
         hipLaunchKernelGGL(gemm_tn_tile, dim3(cdiv(M, 32), cdiv(N, 32), ks), dim3(64), 0, stream, A, B, K, static_cast<int>(M),
                            static_cast<int>(N), ks, dst);
-    if (ks > 1)
+    if (ks > 1 || strided)
         hipLaunchKernelGGL(gemm_tn_reduce, dim3(cdiv(M * N + (colsum_A ? M : 0), 256)), dim3(256), 0, stream, slab, M * N, ks, C,
-                           static_cast<const float*>(colsum_A ? cpart : nullptr), static_cast<int>(M), colsum_A);
+                           static_cast<const float*>(colsum_A ? cpart : nullptr), static_cast<int>(M), colsum_A, static_cast<int>(N), ldc);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

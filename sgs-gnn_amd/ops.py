@@ -232,27 +232,46 @@ class _STWeights(torch.autograd.Function):
         return gp, None, None, None, None
 
 
+_zero_tokens = {}
+
+
+def _zero_token(device) -> torch.Tensor:
+    """One persistent zero per device; `.expand(E)` of it is the "all zeros, look at ActiveSet.gq" gradient below (no launch)."""
+    key = (device.type, device.index)
+    t = _zero_tokens.get(key)
+    if t is None:
+        t = _zero_tokens[key] = torch.zeros(1, dtype=torch.float32, device=device)
+    return t
+
+
 class _SelectSampled(torch.autograd.Function):
     """probs[eid] with the VALUES the sampler's compaction already gathered (sgs_sample_topq's sampled_p): the forward
-    launches nothing; the backward is index_select's (scatter of the q gradients into zeros [E]; the eids are unique)."""
+    launches nothing; the backward is index_select's (scatter of the q gradients into zeros [E]; the eids are unique).
+    With `active` (the scorer's ActiveSet for these very edges, hybrid pipeline) the q gradients are handed to the scorer's
+    backward directly (`active.gq`) and the [E] gradient that autograd wants is a stride-0 view of a persistent zero: the
+    zero-fill of [E], the scatter and the scorer's gather back to [q] -- three launches -- disappear."""
 
     @staticmethod
-    def forward(ctx, probs, eid, values):
+    def forward(ctx, probs, eid, values, active):
         ctx.save_for_backward(eid)
-        ctx.E = probs.numel()
+        ctx.E, ctx.active = probs.numel(), active
         return values.view_as(values)
 
     @staticmethod
     def backward(ctx, g):
         (eid,) = ctx.saved_tensors
+        act = ctx.active
+        if act is not None and act.eid is not None and act.eid.data_ptr() == eid.data_ptr() and act.eid.numel() == eid.numel():
+            act.gq = g.contiguous()
+            return _zero_token(g.device).expand(ctx.E), None, None, None
         gp = torch.zeros(ctx.E, dtype=g.dtype, device=g.device)
         gp.index_copy_(0, eid, g.contiguous())
-        return gp, None, None
+        return gp, None, None, None
 
 
-def select_sampled(probs, eid, values):
+def select_sampled(probs, eid, values, active=None):
     _need_gpu(probs, eid, values)
-    return _SelectSampled.apply(probs, eid, values)
+    return _SelectSampled.apply(probs, eid, values, active)
 
 
 def st_weights(p, prior, c, stats, eid):
@@ -469,10 +488,10 @@ class ActiveSet:
     None = all (dense backward over every scored edge).  The hybrid pipeline sets it to the
     q sampled edges after the draw (every other entry of dL/dp is exactly zero there,
     training_hybrid.py:86), which cuts the scorer's backward from E to q rows."""
-    __slots__ = ("eid", "graph")
+    __slots__ = ("eid", "graph", "gq")
 
     def __init__(self):
-        self.eid, self.graph = None, None
+        self.eid, self.graph, self.gq = None, None, None      # gq: the active rows' upstream gradient, handed over by _SelectSampled
 
     def set(self, eid: torch.Tensor, graph: Graph):
         self.eid, self.graph = eid, graph
@@ -497,11 +516,16 @@ def _endpoint_reduce(M_out, M_in, T, graph: Graph, s_out, s_in, H):
 
 
 class _EdgeScore(torch.autograd.Function):
+    """K1b with the node-level half of fc1 inside: U = codes W1b^T (library GEMM) in forward; in backward d codes gets dU W1b on
+    top of the direct term, and BOTH halves of d fc1.weight [H, 2H] are written in place by the two weight-gradient GEMMs
+    (d W1a = dv^T feat, d W1b = dU^T codes; sgs_gemm_tn_ld with ldc = 2H) -- no slice views, zero fills or gradient adds."""
+
     @staticmethod
-    def forward(ctx, codes, U, W1, b1, w2, b2, edge_index, active, p, seed, site, edge_id_offset):
+    def forward(ctx, codes, W1, b1, w2, b2, edge_index, active, p, seed, site, edge_id_offset):
         L = _lib.lib()
         N, H = codes.shape
         E = edge_index.shape[1]
+        U = torch.mm(codes, W1[:, H:].t())
         out = torch.empty(E, dtype=torch.float32, device=codes.device)
         ws = workspace(L.sgs_edge_score_workspace_bytes(N, H, E), codes.device)
         _lib.check(L.sgs_edge_score_fwd(_ptr(codes, torch.float32), _ptr(U, torch.float32), N, H, _ptr(edge_index, torch.int64), E,
@@ -522,7 +546,14 @@ class _EdgeScore(torch.autograd.Function):
         if act is not None and act.eid is not None:
             eid, graph = act.eid, act.graph
             n = eid.numel()
-            gp_act = gp.index_select(0, eid)
+            tok = _zero_token(dev)
+            if act.gq is not None and gp.numel() == E and gp.stride(0) == 0 and gp.data_ptr() == tok.data_ptr():
+                gp_act = act.gq                     # handed over by _SelectSampled: `gp` is the stride-0 zero, nothing to gather
+            else:
+                gp_act = gp.index_select(0, eid)
+                if act.gq is not None:              # another consumer of the scores contributed a dense gradient as well
+                    gp_act = gp_act + act.gq
+            act.gq = None
         else:
             eid, graph, n = None, get_graph(edge_index, N), E
             gp_act = gp.contiguous()
@@ -547,18 +578,18 @@ class _EdgeScore(torch.autograd.Function):
             # as F.linear with a contiguous W1a^T: the vendor GEMM runs that form at 110 TFLOP/s (85 with the strided view)
             W1a_t = W1[:, :H].t().contiguous()
             dfeat = torch.nn.functional.linear(dv, W1a_t)          # [n,H]
-        # dW1a = dv^T feat (K = n rows): sgs_gemm_tn's tall-K kernel; the vendor GEMM picks a 42 TFLOP/s kernel for this shape
-        dW1 = torch.zeros_like(W1)
-        dW1a = torch.empty(H, H, dtype=torch.float32, device=dev)
+        # d fc1.weight [H, 2H], both halves written in place.  Left: dW1a = dv^T feat (K = n rows): sgs_gemm_tn's tall-K kernel (the
+        # vendor GEMM picks a 42 TFLOP/s kernel for this shape), with d b1 = colsum(dv) as a by-product of the same pass over dv
+        dW1 = torch.empty_like(W1)
         wsg = workspace(L.sgs_gemm_tn_workspace_bytes(n, H, H), dev)
-        if L.sgs_gemm_tn_can_colsum(n, H, H):                  # d b1 = colsum(dv) as a by-product of the same pass over dv
+        if L.sgs_gemm_tn_can_colsum(n, H, H):
             db1 = torch.empty(H, dtype=torch.float32, device=dev)
-            _lib.check(L.sgs_gemm_tn_colsum(_ptr(dv), _ptr(feat), n, H, H, _ptr(dW1a), _ptr(db1), wsg.data_ptr(), wsg.numel(), _stream()),
-                       "sgs_gemm_tn_colsum")
+            _lib.check(L.sgs_gemm_tn_ld(_ptr(dv), _ptr(feat), n, H, H, _ptr(dW1), 2 * H, _ptr(db1), wsg.data_ptr(), wsg.numel(), _stream()),
+                       "sgs_gemm_tn_ld")
         else:
-            _lib.check(L.sgs_gemm_tn(_ptr(dv), _ptr(feat), n, H, H, _ptr(dW1a), wsg.data_ptr(), wsg.numel(), _stream()), "sgs_gemm_tn")
+            _lib.check(L.sgs_gemm_tn_ld(_ptr(dv), _ptr(feat), n, H, H, _ptr(dW1), 2 * H, None, wsg.data_ptr(), wsg.numel(), _stream()),
+                       "sgs_gemm_tn_ld")
             db1 = _colsum(dv)
-        dW1[:, :H] = dW1a                                      # (W1b's half arrives through U)
         dw2 = _colsum(hdz)
         db2 = _colsum(dz.view(n, 1)).reshape(1)
         if H % 4 == 0 and N <= 65536:                          # both endpoint reductions in one pass over the incident-edge lists
@@ -570,17 +601,20 @@ class _EdgeScore(torch.autograd.Function):
         else:
             dcodes = _endpoint_reduce(dfeat, dfeat, codes, graph, 1.0, 1.0, H)
             dU = _endpoint_reduce(dv, dv, None, graph, 1.0, -1.0, H)
-        return dcodes, dU, dW1, db1, dw2, db2, None, None, None, None, None, None
+        # the node-level half: U = codes W1b^T  ->  d codes += dU W1b (library GEMM, accumulating),  d W1b = dU^T codes (right half)
+        if ctx.needs_input_grad[0]:
+            dcodes = torch.addmm(dcodes, dU, W1[:, H:])
+        wsb = workspace(L.sgs_gemm_tn_workspace_bytes(N, H, H), dev)
+        _lib.check(L.sgs_gemm_tn_ld(_ptr(dU), _ptr(codes), N, H, H, dW1.data_ptr() + 4 * H, 2 * H, None, wsb.data_ptr(), wsb.numel(), _stream()),
+                   "sgs_gemm_tn_ld")
+        return dcodes, dW1, db1, dw2, db2, None, None, None, None, None, None
 
 
 def edge_score(codes, fc1_w, fc1_b, fc2_w, fc2_b, edge_index, active=None, p=0.0, seed=0, site=0, edge_id_offset=0):
     """K1b.  codes [N,H]; fc1_w [H,2H]; fc1_b [H]; fc2_w [1,H]; fc2_b [1]; edge_index [2,E] -> p [E]."""
     _need_gpu(codes, fc1_w, edge_index)
-    H = codes.shape[1]
-    U = linear_nobias(codes, fc1_w[:, H:])                 # node-level half of fc1: library GEMM forward, sgs_gemm_tn weight gradient
-    return _EdgeScore.apply(codes.contiguous(), U.contiguous(), fc1_w.contiguous(), fc1_b.contiguous(),
-                            fc2_w.reshape(-1).contiguous(), fc2_b.contiguous(), edge_index.contiguous(), active, float(p),
-                            int(seed), int(site), int(edge_id_offset))
+    return _EdgeScore.apply(codes.contiguous(), fc1_w.contiguous(), fc1_b.contiguous(), fc2_w.reshape(-1).contiguous(), fc2_b.contiguous(),
+                            edge_index.contiguous(), active, float(p), int(seed), int(site), int(edge_id_offset))
 
 
 # ------------------------------------------------------------------ gate + losses (K6)

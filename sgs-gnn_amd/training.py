@@ -113,7 +113,7 @@ def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise
         # edge_probs_full[mask]: gradient reaches only the q sampled entries
         if pass1_active is not None:
             pass1_active.set(smp.eid, graph_s)
-        st.edge_probs_for_loss = ops.select_sampled(st.edge_probs_full, smp.eid, smp.p)    # = edge_probs_full[mask], gathered by the draw
+        st.edge_probs_for_loss = ops.select_sampled(st.edge_probs_full, smp.eid, smp.p, pass1_active)    # = edge_probs_full[mask], gathered by the draw
     elif pipeline == "straight_through":
         st.edge_probs_for_loss = ops.st_weights(st.edge_probs_full, batch.prob, args.degree_bias_coef, smp.stats, smp.eid)
     else:

@@ -324,7 +324,7 @@ def _s5_setup(path=None):
     across processes, so the ranks must not each build their own)."""
     import sgs_gnn_amd as S
     if path is None:
-        b = S.synthetic_graph(232_965, 114_615_892, 602, 41, seed=77, train_frac=0.66, power=0.6, device=DEV)
+        b = S.synthetic_graph(232_965, 114_615_892, 602, 41, seed=77, train_frac=0.66, power=0.35, device=DEV)     # max degree ~2e4, as Reddit (21 657)
     else:
         b = S.Batch(**{k: v.to(DEV) for k, v in torch.load(path, weights_only=True).items()})
     torch.manual_seed(0)

@@ -10,7 +10,7 @@ dev = "cuda:0"
 N, F_, C, H = 232_965, 602, 41, 256
 E_target = int(os.environ.get("S5_EDGES", "114615892"))
 t0 = time.perf_counter()
-b = S.synthetic_graph(N, E_target, F_, C, seed=77, train_frac=0.66, power=0.6, device=dev)
+b = S.synthetic_graph(N, E_target, F_, C, seed=77, train_frac=0.66, power=float(os.environ.get("S5_POWER", "0.35")), device=dev)
 torch.cuda.synchronize()
 E = b.edge_index.shape[1]
 q = int(E * 0.2)
