@@ -160,10 +160,15 @@ __global__ void __launch_bounds__(64) gemm_tn_tall_tile(const float* __restrict_
 // pieces of B (two N-tiles) -- splits the 48 values into three bf16 pieces each and issues 8 tiles x 6 products of
 // v_mfma_f32_32x32x16_bf16.  fp32-faithful like the scorer loop; the VALU work (264 instructions per 48 MFMAs) is at the
 // budget the matrix pipe leaves, so the kernel runs one wave per SIMD with the next step's loads in flight.
-__global__ void __launch_bounds__(64) gemm_tn_tall_bf16x6(const float* __restrict__ A, const float* __restrict__ B, int64_t K, int M, int N,
-                                                         int ksplit, float* __restrict__ slab, float* __restrict__ cpart) {
-    const int lane = threadIdx.x, g = lane >> 5, l31 = lane & 31;
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 64, s = blockIdx.z;
+// NW waves per workgroup, each with its own K-slice (ksplit = NW x gridDim.z slices in all): the NW partial tiles are summed
+// through LDS in a fixed tree before ONE slab per workgroup is written, so the slab reduction that follows reads 1 / NW of the
+// bytes (K = 100 000, M = N = 256: 128 slices -> 32 slabs of 256 KB; the reduction launch drops from 32 us to the launch floor).
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) gemm_tn_tall_bf16x6(const float* __restrict__ A, const float* __restrict__ B, int64_t K, int M, int N,
+                                                              int ksplit, float* __restrict__ slab, float* __restrict__ cpart) {
+    extern __shared__ float red_lds[];       // NW > 1: [NW / 2][8 tiles x 16 registers][64 lanes] partial tiles + [NW / 2][4][64] column sums
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 64, s = blockIdx.z * NW + wave;
     const int ia = m0 + 4 * l31, jb = n0 + 2 * l31;
     const bool aok = ia < M, bok = jb < N;
     const int64_t per = ((K + ksplit - 1) / ksplit + 15) & ~int64_t(15);   // slice length: a whole number of 16-row steps
@@ -241,9 +246,42 @@ __global__ void __launch_bounds__(64) gemm_tn_tall_bf16x6(const float* __restric
     if (want_cs) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) cs[t] += __shfl_xor(cs[t], 32, 64);          // the two 8-row groups of every step
-        if (g == 0 && aok) *reinterpret_cast<float4*>(cpart + static_cast<int64_t>(s) * M + ia) = make_float4(cs[0], cs[1], cs[2], cs[3]);
     }
-    float* out = slab + static_cast<int64_t>(s) * M * N;
+    if (NW > 1) {
+        // fixed tree over the workgroup's waves: upper half stores, lower half adds, halve, repeat (lane-major: conflict-free)
+        float* csl = red_lds + (NW / 2) * 128 * 64;
+#pragma unroll
+        for (int half = NW / 2; half >= 1; half >>= 1) {
+            if (wave >= half && wave < 2 * half) {
+                float* dstp = red_lds + static_cast<size_t>(wave - half) * 128 * 64;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dstp[((t * 2 + u) * 16 + r) * 64 + lane] = acc[t][u][r];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) csl[((wave - half) * 4 + t) * 64 + lane] = cs[t];
+            }
+            __syncthreads();
+            if (wave < half) {
+                const float* srcp = red_lds + static_cast<size_t>(wave) * 128 * 64;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[t][u][r] += srcp[((t * 2 + u) * 16 + r) * 64 + lane];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) cs[t] += csl[(wave * 4 + t) * 64 + lane];
+            }
+            __syncthreads();
+        }
+        if (wave != 0) return;
+    }
+    const int slab_id = blockIdx.z;
+    if (want_cs && g == 0 && aok) *reinterpret_cast<float4*>(cpart + static_cast<int64_t>(slab_id) * M + ia) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+    float* out = slab + static_cast<int64_t>(slab_id) * M * N;
     // accumulator register r of tile (t, w): row m0 + 4 ((r & 3) + 8 (r >> 2) + 4 g) + t, column n0 + 2 l31 + w
     if (bok) {
 #pragma unroll
@@ -325,8 +363,21 @@ static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, in
     float* cpart = cv.take<float>(static_cast<size_t>(ks) * M);
     const bool strided = ldc > 0 && ldc != N;                  // the tile kernels write dense [M, N]: a strided C goes through the reduce
     float* dst = (ks == 1 && !strided) ? C : slab;
-    if (use_tall(K, M, N) && g_tall_bf16x6)
-        hipLaunchKernelGGL(gemm_tn_tall_bf16x6, dim3(cdiv(M, 128), cdiv(N, 64), ks), dim3(64), 0, stream, A, B, K, static_cast<int>(M),
+    int n_slabs = ks;                                          // slabs the reduction launch sums (= K-slices unless waves share a workgroup)
+    if (use_tall(K, M, N) && g_tall_bf16x6 && ks >= 4 && ks % 4 == 0) {
+        constexpr int NW = 4;
+        constexpr size_t lds = (NW / 2) * (128 * 64 + 4 * 64) * sizeof(float);
+        static bool raised = false;
+        if (!raised) {
+            SGS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_tall_bf16x6<NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds)));
+            raised = true;
+        }
+        n_slabs = ks / NW;
+        hipLaunchKernelGGL((gemm_tn_tall_bf16x6<NW>), dim3(cdiv(M, 128), cdiv(N, 64), n_slabs), dim3(64 * NW), lds, stream, A, B, K,
+                           static_cast<int>(M), static_cast<int>(N), ks, slab, colsum_A ? cpart : static_cast<float*>(nullptr));
+    } else if (use_tall(K, M, N) && g_tall_bf16x6)
+        hipLaunchKernelGGL((gemm_tn_tall_bf16x6<1>), dim3(cdiv(M, 128), cdiv(N, 64), ks), dim3(64), 0, stream, A, B, K, static_cast<int>(M),
                            static_cast<int>(N), ks, dst, colsum_A ? cpart : static_cast<float*>(nullptr));
     else if (use_tall(K, M, N))
         hipLaunchKernelGGL(gemm_tn_tall_tile, dim3(cdiv(M, 128), cdiv(N, 64), ks), dim3(64), 0, stream, A, B, K, static_cast<int>(M),
@@ -335,7 +386,7 @@ static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, in
         hipLaunchKernelGGL(gemm_tn_tile, dim3(cdiv(M, 32), cdiv(N, 32), ks), dim3(64), 0, stream, A, B, K, static_cast<int>(M),
                            static_cast<int>(N), ks, dst);
     if (ks > 1 || strided)
-        hipLaunchKernelGGL(gemm_tn_reduce, dim3(cdiv(M * N + (colsum_A ? M : 0), 256)), dim3(256), 0, stream, slab, M * N, ks, C,
+        hipLaunchKernelGGL(gemm_tn_reduce, dim3(cdiv(M * N + (colsum_A ? M : 0), 256)), dim3(256), 0, stream, slab, M * N, n_slabs, C,
                            static_cast<const float*>(colsum_A ? cpart : nullptr), static_cast<int>(M), colsum_A, static_cast<int>(N), ldc);
     SGS_LAUNCH_OK();
     return SGS_OK;

@@ -603,7 +603,7 @@ class _EdgeScore(torch.autograd.Function):
             dU = _endpoint_reduce(dv, dv, None, graph, 1.0, -1.0, H)
         # the node-level half: U = codes W1b^T  ->  d codes += dU W1b (library GEMM, accumulating),  d W1b = dU^T codes (right half)
         if ctx.needs_input_grad[0]:
-            dcodes = torch.addmm(dcodes, dU, W1[:, H:])
+            dcodes.addmm_(dU, W1[:, H:])                           # in place (beta = 1): no copy of dcodes
         wsb = workspace(L.sgs_gemm_tn_workspace_bytes(N, H, H), dev)
         _lib.check(L.sgs_gemm_tn_ld(_ptr(dU), _ptr(codes), N, H, H, dW1.data_ptr() + 4 * H, 2 * H, None, wsb.data_ptr(), wsb.numel(), _stream()),
                    "sgs_gemm_tn_ld")

@@ -24,8 +24,13 @@ class FusedAdam(torch.optim.Optimizer):
                         foreach=None, fused=None, differentiable=False)
         super().__init__(params, defaults)
         self._tickets = {}
+        self._ticket_pool = None          # one zero-initialised int32 block per optimiser; a launch's ticket is a view of it
 
     def _init_state(self, p):
+        if self._ticket_pool is None:
+            # created with the state, i.e. BEFORE any capture: a ticket born inside a capture would be re-zeroed by a fill kernel on
+            # every replay (5 us per optimiser step at partition scale)
+            self._ticket_pool = torch.zeros(64, dtype=torch.int32, device=p.device)
         st = self.state[p]
         if len(st) == 0:
             st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
@@ -68,7 +73,11 @@ class FusedAdam(torch.optim.Optimizer):
                 key = (gi, lo)
                 tk = self._tickets.get(key)
                 if tk is None:
-                    tk = self._tickets[key] = torch.zeros(1, dtype=torch.int32, device=part[0].device)
+                    if self._ticket_pool is not None and len(self._tickets) < self._ticket_pool.numel():
+                        i = len(self._tickets)
+                        tk = self._tickets[key] = self._ticket_pool[i:i + 1]
+                    else:
+                        tk = self._tickets[key] = torch.zeros(1, dtype=torch.int32, device=part[0].device)
                 arr = (ctypes.c_int64 * len(words))(*words)
                 _lib.check(L.sgs_adam_step(arr, len(part), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                            float(group["weight_decay"]), int(bool(group["maximize"])), tk.data_ptr(), stream),
