@@ -20,10 +20,11 @@ def load(d, needle):
     return dict(avg), sum(dur[k] for k in ks) / len(ks), len(ks)
 
 d_sq, d_f, d_w, needle, out = sys.argv[1:6]
+E_ARG = int(sys.argv[6]) if len(sys.argv) > 6 else 351194
 sq, dur, n = load(d_sq, needle)
 fe, _, _ = load(d_f, needle)
 wr, _, _ = load(d_w, needle)
-E, N, H = 351194, 1013, 256
+E, N, H = E_ARG, 1013, 256
 clock = sq["GRBM_GUI_ACTIVE"] / 8 / (dur * 1e-6) / 1e9                 # guide: counter is the sum over the 8 XCDs
 simds = 256 * 4
 mfma_busy = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (sq["GRBM_GUI_ACTIVE"] / 8 * simds)      # pipe-busy cycles / SIMD cycles
@@ -32,7 +33,7 @@ fetch_kb, write_kb = fe["FETCH_SIZE"], wr["WRITE_SIZE"]
 hit, miss = wr.get("TCC_HIT_sum", 0.0), wr.get("TCC_MISS_sum", 0.0)
 rec = {
     "kernel": f"{needle} (sgs_edge_score_fwd), E={E}, N={N}, H={H}, dropout 0.3",
-    "command": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 tools/prof_scorer.py 351194 6  (three separate passes)",
+    "command": f"rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 tools/prof_scorer.py {E} 6  (three separate passes)",
     "dispatches_averaged": n,
     "avg_duration_us_under_pmc": round(dur, 1),
     "effective_clock_GHz": round(clock, 3),
@@ -45,7 +46,7 @@ rec = {
     "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None,
     "hbm_traffic_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
     "traffic_note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16-B/lane reads); gathers are 16 B/lane. "
-                    "Algorithmic HBM bytes per launch: 16 B x E edge ids + 4 B x E output + node tables (codes, U: 2 x 1 MB) + W1a (256 KB fp32, 384 KB as bf16 pieces) = 9.4 MB; "
+                    "Algorithmic HBM bytes per launch: 16 B x E edge ids + 4 B x E output + node tables (codes, U: 2 x 1 MB) + W1a (256 KB fp32, 384 KB as bf16 pieces) = 20 B x E + 2.4 MB; "
                     "the table re-reads are L2 hits.",
 }
 json.dump(rec, open(out, "w"), indent=1)
