@@ -322,6 +322,21 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
                        int64_t edge_id_offset, const float* W1, const float* b1, const float* w2, const float* b2,
                        float p_drop, uint64_t seed, uint32_t site, float* p_out, void* ws, size_t ws_bytes,
                        sgs_stream_t stream);
+/* Paired forward.  fc1's edge-level half W1a (x_s * x_d) is symmetric in the endpoints, so on an undirected graph stored in both
+ * directions (every dataset of the reference: datasets.py:189-190) an edge and its reverse share that contraction bit for bit; they
+ * differ in the sign of U[s] - U[d] and in their dropout rows.  sgs_edge_mates pairs the edges (mate[e] = id of (dst_e -> src_e)
+ * or -1; mutual, one to one; needs the src-CSR of sgs_graph_build), the caller lists the canonical edges (mate < 0 or e < mate)
+ * and sgs_edge_score_fwd_paired runs the H x H contraction for those M edges only, finishing both scores of a pair in its
+ * epilogue: p_out [E] equals sgs_edge_score_fwd's bit for bit.  H = 128 or 256 (ask sgs_edge_score_paired_supported).
+ * Under sgs_dyn_edges_set the live M is read from word 1 of the registered dims (word 0 = live E). */
+size_t sgs_edge_mates_workspace_bytes(int64_t n_edges);
+int sgs_edge_mates(const int64_t* edge_index, int64_t n_edges, int64_t N, const int32_t* out_ptr, const int32_t* out_dst,
+                   const int32_t* out_eid, int32_t* mate, void* ws, size_t ws_bytes, sgs_stream_t stream);
+int sgs_edge_score_paired_supported(int64_t H);
+int sgs_edge_score_fwd_paired(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
+                              int64_t edge_id_offset, const int32_t* canon, int64_t M, const int32_t* mate, const float* W1, const float* b1,
+                              const float* w2, const float* b2, float p_drop, uint64_t seed, uint32_t site, float* p_out, void* ws,
+                              size_t ws_bytes, sgs_stream_t stream);
 int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index,
                             int64_t E, int64_t edge_id_offset, const int64_t* active_eid, int64_t n_active, const float* grad_p,
                             const float* W1, const float* b1, const float* w2, const float* b2, float p_drop,

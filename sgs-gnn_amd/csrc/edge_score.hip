@@ -49,6 +49,8 @@ struct ScoreArgs {
     const int64_t* dst;      // [E]
     const int64_t* active;   // [n] edge ids (backward) or nullptr = identity
     int64_t n;               // rows processed (E forward, n_active backward)
+    const int32_t* canon;    // paired forward (MODE 3): [n] ids of the edges processed here; each also produces the score of its mate
+    const int32_t* mate;     // paired forward: [E] id of the reverse edge (d -> s) of edge (s -> d), or -1
     const int64_t* dyn_n;    // forward under sgs_dyn_edges_set: the live row count is read from this device word; `n` is then only the
                              // capacity the grid was sized for (HIP-graph replay of one captured step over partitions of any size)
     int64_t row_offset;      // global id of local edge 0 (edge-sharded graphs): dropout rows are global edge ids
@@ -728,9 +730,15 @@ __global__ void __launch_bounds__(kT) pack_w1a_bf16x3(const float* __restrict__ 
 // MODE 2: the loop as a row GEMM, out[r, :] = in[r, :] . M for a dense [n, H] input (a.codes -> a.feat): the backward's
 // dfeat = dv W1a, with `Wp16` packed from the TRANSPOSED matrix (pack_w1a_bf16x3<true>); no gather, no product, the
 // accumulators are the result.
+// MODE 3: the PAIRED forward.  fc1's heavy half W1a (x_s * x_d) is symmetric in the endpoints: on an undirected graph stored in
+// both directions (every dataset of the reference: datasets.py:189-190 to_undirected) the edge (s -> d) and its mate (d -> s)
+// share that contraction bit for bit (a * b == b * a in fp32, same operands, same order of accumulation) and differ only in the
+// sign of the node-level term U[s] - U[d] and in their dropout rows.  So only the canonical edge of every mated pair (and every
+// unmated edge) runs the main loop -- about half of the candidate edges -- and the epilogue finishes BOTH scores from the one
+// set of accumulators: the same p as MODE 0, bit for bit, at ~0.6 x the time.
 template <int NT, int NW, int MODE = 0>
 __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(ScoreArgs a, const uint4* __restrict__ Wp16) {
-    constexpr bool BWD = MODE == 1, GEMM = MODE == 2;
+    constexpr bool BWD = MODE == 1, GEMM = MODE == 2, PAIR = MODE == 3;
     constexpr int H = 32 * NT;
     constexpr int NPH = H / 16;              // phases: one 16-deep k-chunk each, one barrier per phase
     constexpr int CH = NT * 3 * 64;          // 16-byte words per k-chunk of W1a (all hidden units, three pieces)
@@ -754,7 +762,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
     int s = 0, d = 0;
     int64_t eg_id = 0;
     if (live && !GEMM) {
-        eg_id = a.active ? a.active[r] : r;
+        eg_id = PAIR ? static_cast<int64_t>(a.canon[r]) : (a.active ? a.active[r] : r);
         s = static_cast<int>(a.src[eg_id]);
         d = static_cast<int>(a.dst[eg_id]);
     }
@@ -871,6 +879,13 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
     constexpr int kPF = 8;
     const int Hrt = a.H;
     const uint32_t rkey = dropout_row_key(fold_epoch(a.seed, a.epoch), a.site, static_cast<uint64_t>(a.row_offset + eg_id));
+    int64_t mate_id = -1;                                         // MODE 3: the reverse edge, finished from the same accumulators
+    uint32_t rkey2 = 0u;
+    float z2 = 0.f;
+    if constexpr (PAIR) {
+        if (live) mate_id = a.mate[eg_id];
+        rkey2 = dropout_row_key(fold_epoch(a.seed, a.epoch), a.site, static_cast<uint64_t>(a.row_offset + (mate_id >= 0 ? mate_id : 0)));
+    }
     const float* Us = a.U + static_cast<int64_t>(s) * H + 4 * kh;
     const float* Ud = a.U + static_cast<int64_t>(d) * H + 4 * kh;
     float4 us[kPF], ud[kPF];
@@ -900,6 +915,25 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
                 bits[0] = dropout_pair_bits(rkey, static_cast<uint32_t>(hb >> 1));
                 bits[1] = dropout_pair_bits(rkey, static_cast<uint32_t>((hb >> 1) + 1));
             }
+            if constexpr (PAIR) {
+                // the mate (d -> s): same accumulators, node-level term U[d] - U[s] (the exact negation), its own dropout row
+                const float n4[4] = {du.x - su.x, du.y - su.y, du.z - su.z, du.w - su.w};
+                uint32_t bits2[2] = {0u, 0u};
+                if (a.use_drop) {
+                    bits2[0] = dropout_pair_bits(rkey2, static_cast<uint32_t>(hb >> 1));
+                    bits2[1] = dropout_pair_bits(rkey2, static_cast<uint32_t>((hb >> 1) + 1));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v2 = (acc[t][4 * g4 + j] + n4[j]) + b4[j];
+                    float m2 = v2 > 0.f ? 1.f : 0.f;
+                    if (a.use_drop) {
+                        const uint32_t draw2 = (j & 1) ? (bits2[j >> 1] >> 16) : (bits2[j >> 1] & 0xFFFFu);
+                        m2 = draw2 >= a.drop_thresh ? m2 * a.drop_scale : 0.f;
+                    }
+                    z2 = fmaf(w4[j], v2 * m2, z2);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float v = (acc[t][4 * g4 + j] + u4[j]) + b4[j];
@@ -915,6 +949,14 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
         }
     }
     z += __shfl_xor(z, 32, 64);
+    if constexpr (PAIR) {
+        z2 += __shfl_xor(z2, 32, 64);
+        if (live && kh == 0) {
+            a.p_out[eg_id] = 1.0f / (1.0f + expf(-(z + a.b2[0])));
+            if (mate_id >= 0) a.p_out[mate_id] = 1.0f / (1.0f + expf(-(z2 + a.b2[0])));
+        }
+        return;
+    }
     if (!BWD) {
         if (live && kh == 0) {
             const float zz = z + a.b2[0];
@@ -1422,6 +1464,43 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
     }
     hipLaunchKernelGGL(transpose_w1a, dim3(cdiv(H, 32), cdiv(H, 32)), dim3(kT), 0, stream, W1, static_cast<int>(H), WaT);
     return launch_score<false>(a, stream);
+}
+
+/* Paired forward (sgs_hip.h): only the `M` canonical edges run the H x H contraction; each also finishes its mate's score. */
+int sgs_edge_score_paired_supported(int64_t H) { return (H == 128 || H == 256) ? 1 : 0; }
+
+int sgs_edge_score_fwd_paired(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
+                              int64_t edge_id_offset, const int32_t* canon, int64_t M, const int32_t* mate, const float* W1, const float* b1,
+                              const float* w2, const float* b2, float p_drop, uint64_t seed, uint32_t site, float* p_out, void* ws,
+                              size_t ws_bytes, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (int rc = check_common("sgs_edge_score_fwd_paired", N, H, E, p_drop)) return rc;
+    SGS_REQUIRE(sgs_edge_score_paired_supported(H), SGS_EINVAL, "sgs_edge_score_fwd_paired: H must be 128 or 256");
+    SGS_REQUIRE(M >= 0 && M <= E, SGS_EINVAL, "sgs_edge_score_fwd_paired: bad canonical count");
+    if (E == 0 || M == 0) return SGS_OK;
+    SGS_REQUIRE(codes && U && edge_index && canon && mate && W1 && b1 && w2 && b2 && p_out, SGS_EINVAL, "sgs_edge_score_fwd_paired: null pointer");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_workspace_bytes(N, H, E), SGS_EWORKSPACE, "sgs_edge_score_fwd_paired: workspace too small");
+    Carver cv(ws);
+    cv.take<float>(static_cast<size_t>(H) * H);
+    cv.take<float>(static_cast<size_t>(N) * H);
+    cv.take<float>(2 * static_cast<size_t>(E));
+    cv.take<unsigned int>(64);
+    uint4* Wp16 = cv.take<uint4>(static_cast<size_t>(H) * H * 6 / 16);
+    ScoreArgs a{};
+    a.codes = codes; a.U = U; a.src = edge_index; a.dst = edge_index + E; a.active = nullptr; a.n = M; a.H = static_cast<int>(H);
+    a.row_offset = edge_id_offset;
+    a.b1 = b1; a.w2 = w2; a.b2 = b2;
+    a.drop_scale = 1.0f / (1.0f - p_drop); a.drop_thresh = dropout_thresh(p_drop); a.seed = seed; a.epoch = epoch_ptr(); a.site = site;
+    a.use_drop = p_drop > 0.f; a.p_out = p_out;
+    a.canon = canon; a.mate = mate;
+    a.dyn_n = dyn_edges_ptr() ? dyn_edges_ptr() + 1 : nullptr;       // word 1 of the registered dims: the live number of canonical edges
+    hipLaunchKernelGGL(pack_w1a_bf16x3<false>, dim3(static_cast<unsigned>(cdiv((H / 16) * (H / 32) * 64, kT))), dim3(kT), 0, stream, W1,
+                       static_cast<int>(H), Wp16);
+    const dim3 grid(static_cast<unsigned>(cdiv(M, 128))), blk(256);
+    if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4, 3>), grid, blk, 0, stream, a, Wp16);
+    else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4, 3>), grid, blk, 0, stream, a, Wp16);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
 }
 
 /* Backward core over the active rows: recomputes the hidden layer and writes

@@ -507,6 +507,31 @@ __device__ __forceinline__ void fma_vec(float4& a, float w, const float4& x) {
 }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// ---------------------------------------------------------------------------------------------
+// Mates: mate[e] = id of the reverse edge (dst_e -> src_e) of edge e, or -1 -- the pairing behind the paired scorer forward
+// (edge_score.hip MODE 3).  rev[e]: binary search for src_e in the out-row of dst_e (rows of a coalesced, row-sorted edge list are
+// ascending in dst; on any other list the search may simply miss and the edge stays unmated, which only costs speed); a mate
+// is kept only when the relation is mutual, so duplicates pair off one to one and self loops stay alone.
+__global__ void __launch_bounds__(kT) edge_reverse(const int64_t* __restrict__ ei, int64_t n, const int* __restrict__ out_ptr,
+                                                  const int* __restrict__ out_dst, const int* __restrict__ out_eid, int* __restrict__ rev) {
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (e >= n) return;
+    const int s = static_cast<int>(ei[e]), d = static_cast<int>(ei[n + e]);
+    int lo = out_ptr[d], hi = out_ptr[d + 1];
+    const int end = hi;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (out_dst[mid] < s) lo = mid + 1; else hi = mid;
+    }
+    rev[e] = (lo < end && out_dst[lo] == s) ? out_eid[lo] : -1;
+}
+__global__ void __launch_bounds__(kT) edge_mate(const int* __restrict__ rev, int64_t n, int* __restrict__ mate) {
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (e >= n) return;
+    const int m = rev[e];
+    mate[e] = (m >= 0 && m != e && rev[m] == static_cast<int>(e)) ? m : -1;
+}
+
 template <int VEC, int LPR>
 __global__ void __launch_bounds__(kT) spmm_csr(const float* __restrict__ X, int64_t N, int64_t D, const int* __restrict__ ptr,
                                               const int* __restrict__ col, const float* __restrict__ val,
@@ -896,6 +921,24 @@ int sgs_graph_filter(const int32_t* pin_ptr, const int32_t* pin_src, const int32
         hipLaunchKernelGGL(filter_fill<false>, g3, blk, 0, stream, pin_ptr, pin_src, pin_eid, pout_ptr, pout_dst, pout_eid, N, mask, pos, in_ptr,
                            in_src, in_eid, out_ptr, out_dst, out_eid, loop_eid);
     }
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+size_t sgs_edge_mates_workspace_bytes(int64_t n_edges) { return carve_bytes(n_edges < 0 ? 0 : n_edges, 4) + 256; }
+
+int sgs_edge_mates(const int64_t* edge_index, int64_t n_edges, int64_t N, const int32_t* out_ptr, const int32_t* out_dst,
+                   const int32_t* out_eid, int32_t* mate, void* ws, size_t ws_bytes, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(n_edges >= 0 && N >= 0 && n_edges < (int64_t(1) << 31), SGS_EINVAL, "sgs_edge_mates: bad sizes");
+    if (n_edges == 0) return SGS_OK;
+    SGS_REQUIRE(edge_index && out_ptr && out_dst && out_eid && mate, SGS_EINVAL, "sgs_edge_mates: null pointer");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_mates_workspace_bytes(n_edges), SGS_EWORKSPACE, "sgs_edge_mates: workspace too small");
+    Carver cv(ws);
+    int* rev = cv.take<int>(n_edges);
+    const dim3 g(static_cast<unsigned>(cdiv(n_edges, kT))), blk(kT);
+    hipLaunchKernelGGL(edge_reverse, g, blk, 0, stream, edge_index, n_edges, out_ptr, out_dst, out_eid, rev);
+    hipLaunchKernelGGL(edge_mate, g, blk, 0, stream, rev, n_edges, mate);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

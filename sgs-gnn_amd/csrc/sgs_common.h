@@ -171,16 +171,18 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t 
     return Philox4{{c0, c1, c2, c3}};
 }
 
-// Exp(1) draw number `e` of stream (seed, stream_id): u = (k + 1/2) 2^-23, k = 23 random bits, so
-// u is exact in fp32 and lies in [2^-24, 1 - 2^-24] (never 0 or 1); noise = -log(u) in (0, 16.7).
+// Exp(1) draw number `e` of stream (seed, stream_id): noise = -log1p(-v) with v = (x + 1/2) 2^-32 from all 32 random bits.
+// The race's WINNERS are the edges with the smallest noise, so that tail must not be coarse: v keeps 24 significant bits down to
+// 2^-33 (noise resolved to ~1e-17 near 0; a 23-bit uniform would quantise it to 1.2e-7 and bias draws with q / E below ~1e-4).
+// v is clamped below 1 (noise <= 16.6: a tail of probability 6e-8 that can only lose the race); noise is never 0.
 __device__ __forceinline__ float exp_noise_at(uint64_t seed, uint64_t stream_id, uint64_t e) {
     const uint64_t blk = e >> 2;
     Philox4 r = philox4x32_10(static_cast<uint32_t>(blk), static_cast<uint32_t>(blk >> 32),
                               static_cast<uint32_t>(stream_id), static_cast<uint32_t>(stream_id >> 32),
                               static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
     const uint32_t x = r.v[e & 3];
-    const float u = (static_cast<float>(x >> 9) + 0.5f) * (1.0f / 8388608.0f);
-    return -logf(u);
+    const float v = fminf((static_cast<float>(x) + 0.5f) * 2.3283064365386963e-10f, 0.99999994f);
+    return -log1pf(-v);
 }
 
 // Dropout keep decision for element (row, col) of dropout site `site`: a 64-bit murmur-style mix of

@@ -44,6 +44,7 @@ def _run(args, model, cluster_loader, device, q, mode, n_draws):
             ops.new_memo_scope()
             edge_probs = None
             if mode == 'learned' and batch.edge_index.shape[1] > q:
+                ops.get_pairs(batch.edge_index, batch.x.shape[0], build=True)     # once per partition (cached)
                 edge_probs = model.edge_prob_mlp(batch.x, batch.edge_index).squeeze()         # encoder over the FULL batch graph
             out = None
             for _ in range(n_draws):

@@ -137,8 +137,8 @@ def set_dyn_edges(word) -> None:
     L = _lib.lib()
     if word is not None:
         _need_gpu(word)
-        if word.dtype != torch.int64 or word.numel() != 1:
-            raise RuntimeError("sgs_gnn_amd: the dynamic edge count is one int64 device word")
+        if word.dtype != torch.int64 or word.numel() not in (1, 2):
+            raise RuntimeError("sgs_gnn_amd: the dynamic sizes are one or two int64 device words (live E[, live canonical edges])")
     _lib.check(L.sgs_dyn_edges_set(None if word is None else word.data_ptr()), "sgs_dyn_edges_set")
     _dyn_edges = word
 
@@ -162,6 +162,13 @@ def dropout_keep(seed: int, site: int, rows: int, cols: int, p: float, device) -
 # ------------------------------------------------------------------ sampler
 class SampleResult:
     __slots__ = ("mask", "eid", "edge_index", "p", "stats", "keys", "E", "q")
+
+    def check(self) -> None:
+        """torch.multinomial(replacement=False) raises when fewer than q categories have a positive weight; the fused draw cannot
+        raise from the device.  It reports the case through `stats`: the threshold key is then 0 (zero-weight edges were admitted
+        by the lowest-id tie-break).  Calling this reads stats back (one synchronisation) and raises like the reference."""
+        if self.q > 0 and float(self.stats[2]) <= 0.0:
+            raise RuntimeError("invalid multinomial distribution (with replacement=False, not enough non-negative category to sample)")
 
 
 def sample_topq(mode: int, p: torch.Tensor, prior, c: float, q: int, edge_index, noise=None, seed: int = 0,
@@ -354,6 +361,34 @@ def get_graph(edge_index: torch.Tensor, N: int) -> Graph:
     return g
 
 
+def get_pairs(edge_index: torch.Tensor, N: int, build: bool = False):
+    """(canon int32 [M], mate int32 [E]) of the paired scorer forward (sgs_edge_mates / sgs_edge_score_fwd_paired), cached on the
+    tensor like its Graph; None when it has not been built.  `build=True` builds it (two launches over the cached CSR + one
+    compaction with a read-back of M: set-up work, done once per partition by the trainers, never inside a captured step)."""
+    c = getattr(edge_index, "_sgs_pairs", None)
+    if c is not None and c[2] == edge_index._version:
+        return c[0], c[1]
+    if not build:
+        return None
+    L = _lib.lib()
+    _need_gpu(edge_index)
+    g = get_graph(edge_index, N)
+    E = g.n_edges
+    dev = edge_index.device
+    mate = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    if E > 0:
+        ws = workspace(L.sgs_edge_mates_workspace_bytes(E), dev)
+        _lib.check(L.sgs_edge_mates(_ptr(g.edge_index), E, N, _ptr(g.out_ptr), _ptr(g.out_dst), _ptr(g.out_eid), _ptr(mate), ws.data_ptr(),
+                                    ws.numel(), _stream()), "sgs_edge_mates")
+    ar = torch.arange(E, dtype=torch.int32, device=dev)
+    canon = ar[(mate[:E] < 0) | (ar < mate[:E])].contiguous()
+    try:
+        edge_index._sgs_pairs = (canon, mate, edge_index._version)
+    except Exception:
+        pass
+    return canon, mate
+
+
 class Norm:
     """gcn_norm result for (graph, w): dis, loopw and the normalised weights in both CSR orders.
     `handle` is the autograd edge through which the layers' gradients wrt the normalised
@@ -521,16 +556,24 @@ class _EdgeScore(torch.autograd.Function):
     (d W1a = dv^T feat, d W1b = dU^T codes; sgs_gemm_tn_ld with ldc = 2H) -- no slice views, zero fills or gradient adds."""
 
     @staticmethod
-    def forward(ctx, codes, W1, b1, w2, b2, edge_index, active, p, seed, site, edge_id_offset):
+    def forward(ctx, codes, W1, b1, w2, b2, edge_index, active, p, seed, site, edge_id_offset, pairs):
         L = _lib.lib()
         N, H = codes.shape
         E = edge_index.shape[1]
         U = torch.mm(codes, W1[:, H:].t())
         out = torch.empty(E, dtype=torch.float32, device=codes.device)
         ws = workspace(L.sgs_edge_score_workspace_bytes(N, H, E), codes.device)
-        _lib.check(L.sgs_edge_score_fwd(_ptr(codes, torch.float32), _ptr(U, torch.float32), N, H, _ptr(edge_index, torch.int64), E,
-                                        edge_id_offset, _ptr(W1, torch.float32), _ptr(b1), _ptr(w2), _ptr(b2), float(p), seed, site, _ptr(out),
-                                        ws.data_ptr(), ws.numel(), _stream()), "sgs_edge_score_fwd")
+        if pairs is not None and E >= 65536 and L.sgs_edge_score_paired_supported(H):
+            # undirected graph stored both ways: the canonical half of the edges runs the contraction, every mate rides along
+            canon, mate = pairs
+            _lib.check(L.sgs_edge_score_fwd_paired(_ptr(codes, torch.float32), _ptr(U, torch.float32), N, H, _ptr(edge_index, torch.int64), E,
+                                                   edge_id_offset, _ptr(canon, torch.int32), canon.numel(), _ptr(mate, torch.int32),
+                                                   _ptr(W1, torch.float32), _ptr(b1), _ptr(w2), _ptr(b2), float(p), seed, site, _ptr(out),
+                                                   ws.data_ptr(), ws.numel(), _stream()), "sgs_edge_score_fwd_paired")
+        else:
+            _lib.check(L.sgs_edge_score_fwd(_ptr(codes, torch.float32), _ptr(U, torch.float32), N, H, _ptr(edge_index, torch.int64), E,
+                                            edge_id_offset, _ptr(W1, torch.float32), _ptr(b1), _ptr(w2), _ptr(b2), float(p), seed, site, _ptr(out),
+                                            ws.data_ptr(), ws.numel(), _stream()), "sgs_edge_score_fwd")
         ctx.save_for_backward(codes, U, W1, b1, w2, b2, edge_index)
         ctx.active, ctx.p, ctx.seed, ctx.site, ctx.offset = active, float(p), seed, site, edge_id_offset
         return out
@@ -607,14 +650,18 @@ class _EdgeScore(torch.autograd.Function):
         wsb = workspace(L.sgs_gemm_tn_workspace_bytes(N, H, H), dev)
         _lib.check(L.sgs_gemm_tn_ld(_ptr(dU), _ptr(codes), N, H, H, dW1.data_ptr() + 4 * H, 2 * H, None, wsb.data_ptr(), wsb.numel(), _stream()),
                    "sgs_gemm_tn_ld")
-        return dcodes, dW1, db1, dw2, db2, None, None, None, None, None, None
+        return dcodes, dW1, db1, dw2, db2, None, None, None, None, None, None, None
 
 
-def edge_score(codes, fc1_w, fc1_b, fc2_w, fc2_b, edge_index, active=None, p=0.0, seed=0, site=0, edge_id_offset=0):
-    """K1b.  codes [N,H]; fc1_w [H,2H]; fc1_b [H]; fc2_w [1,H]; fc2_b [1]; edge_index [2,E] -> p [E]."""
+def edge_score(codes, fc1_w, fc1_b, fc2_w, fc2_b, edge_index, active=None, p=0.0, seed=0, site=0, edge_id_offset=0, pairs="cached"):
+    """K1b.  codes [N,H]; fc1_w [H,2H]; fc1_b [H]; fc2_w [1,H]; fc2_b [1]; edge_index [2,E] -> p [E].
+    `pairs`: (canon, mate) of get_pairs for the paired forward, None for the plain one, "cached" (default) = whatever
+    get_pairs(edge_index) holds (nothing is built here)."""
     _need_gpu(codes, fc1_w, edge_index)
+    if isinstance(pairs, str):
+        pairs = get_pairs(edge_index, codes.shape[0]) if edge_id_offset == 0 else None
     return _EdgeScore.apply(codes.contiguous(), fc1_w.contiguous(), fc1_b.contiguous(), fc2_w.reshape(-1).contiguous(), fc2_b.contiguous(),
-                            edge_index.contiguous(), active, float(p), int(seed), int(site), int(edge_id_offset))
+                            edge_index.contiguous(), active, float(p), int(seed), int(site), int(edge_id_offset), pairs)
 
 
 # ------------------------------------------------------------------ gate + losses (K6)

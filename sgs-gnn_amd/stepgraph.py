@@ -128,7 +128,7 @@ def _round_up(v: int, m: int) -> int:
 
 class _Slot:
     """Static input buffers of one captured step + its graphs."""
-    __slots__ = ("sampled", "index", "npad", "ecap", "batch", "dims", "graph", "norm", "mask4", "g0", "g1", "g2l", "g2r", "cbuf", "loss",
+    __slots__ = ("sampled", "index", "npad", "ecap", "batch", "dims", "graph", "norm", "mask4", "canon", "mate", "g0", "g1", "g2l", "g2r", "cbuf", "loss",
                  "loss_l", "loss_r", "grads", "grads_l", "grads_r", "keep", "pre_event", "pre_epoch", "staged", "stage_event", "live")
 
 
@@ -186,6 +186,8 @@ class StepGraphs:
         self.slots = {True: [], False: []}              # sampled? -> [_Slot, _Slot]
         self.turn = {True: 0, False: 0}
         self.npad, self.ecap = 0, {True: 0, False: 0}   # capacities (nodes; candidate edges per kind)
+        fc1 = getattr(getattr(model, "edge_prob_mlp", None), "fc1", None)
+        self.pairs_ok = fc1 is not None and bool(_lib.lib().sgs_edge_score_paired_supported(int(fc1.weight.shape[0])))
         self.nfeat = None
         self.stage_cache = {}                           # (batch key, slot id) -> (descriptor array, n segments, dims array, keep-alive)
         self.capture_seconds = 0.0
@@ -251,7 +253,7 @@ class StepGraphs:
             n = max(n, int(b.x.shape[0]))
             e[E > self.q] = max(e[E > self.q], E)
             if b.x.is_cuda and E > 0:
-                self._sources(b, want_norm=E <= self.q)      # CSR (+ unit normalisation) of every resident partition, once, up front
+                self._sources(b, want_norm=E <= self.q, want_pairs=E > self.q and self.pairs_ok)   # CSR (+ unit norm / mates) of every resident partition, once
         self._set_capacity(n, e)
 
     def _set_capacity(self, n, e) -> None:
@@ -285,7 +287,7 @@ class StepGraphs:
         ei = torch.zeros(2, Ecap, dtype=torch.int64, **z)
         prob = torch.zeros(Ecap, dtype=torch.float32, **z) if sampled else None
         s.batch = Batch(x=x, edge_index=ei, y=y, train_mask=tm, prob=prob)
-        s.dims = torch.zeros(1, dtype=torch.int64, **z)
+        s.dims = torch.zeros(2, dtype=torch.int64, **z)             # live E; live number of canonical edges (paired scorer forward)
         # the slot's "cached parent graph": same object layout as ops.Graph, arrays filled by the staging copy
         g = ops.Graph.__new__(ops.Graph)
         g.edge_index, g.n_edges, g.N = ei, Ecap, N
@@ -295,6 +297,10 @@ class StepGraphs:
         g.loop_eid = torch.full((max(N, 1),), -1, **i32)
         ei._sgs_graph, ei._sgs_graph_version = g, ei._version
         s.graph = g
+        if sampled and self.pairs_ok:
+            # mates of the paired scorer forward: static buffers filled by the staging copy, their live length in dims[1]
+            s.canon, s.mate = torch.zeros(max(Ecap, 1), **i32), torch.full((max(Ecap, 1),), -1, **i32)
+            ei._sgs_pairs = (s.canon, s.mate, ei._version)
         if not sampled:
             nm = ops.Norm()
             nm.graph, nm.w, nm.handle = g, None, None
@@ -308,7 +314,7 @@ class StepGraphs:
         return s
 
     @staticmethod
-    def _sources(batch, want_norm=False):
+    def _sources(batch, want_norm=False, want_pairs=False):
         """The partition's resident arrays the staging copy reads (built once per partition, cached on the batch): its tensors,
         the CSR of its edge list and -- for the unsampled step -- the unit normalisation; the train mask as whole 4-byte words.
         Launches kernels that take scratch from the MAIN arena: call it on the main stream only (never on the prefetch stream,
@@ -316,12 +322,15 @@ class StepGraphs:
         src = getattr(batch, "_sgs_stage_src", None)
         if src is not None and want_norm and src["norm"] is None:
             src["norm"] = ops.gcn_norm(src["graph"], None)
+        if src is not None and want_pairs and src["pairs"] is None:
+            src["pairs"] = ops.get_pairs(batch.edge_index, int(batch.x.shape[0]), build=True)
         if src is None:
             N = int(batch.x.shape[0])
             g = ops.get_graph(batch.edge_index, N)
             m4 = torch.zeros(_round_up(N, 4), dtype=torch.uint8, device=batch.x.device)
             m4[:N] = ops._u8(batch.train_mask)
-            src = dict(graph=g, mask4=m4, x=batch.x.contiguous(), y=batch.y.contiguous(), norm=ops.gcn_norm(g, None) if want_norm else None)
+            src = dict(graph=g, mask4=m4, x=batch.x.contiguous(), y=batch.y.contiguous(), norm=ops.gcn_norm(g, None) if want_norm else None,
+                       pairs=ops.get_pairs(batch.edge_index, N, build=True) if want_pairs else None)
             try:
                 batch._sgs_stage_src = src
             except Exception:
@@ -333,7 +342,7 @@ class StepGraphs:
         hit = self.stage_cache.get(key)
         if hit is not None:
             return hit
-        src = self._sources(batch, want_norm=not slot.sampled)
+        src = self._sources(batch, want_norm=not slot.sampled, want_pairs=slot.sampled and slot.canon is not None)
         g, sg = src["graph"], slot.graph
         N, E = int(batch.x.shape[0]), int(batch.edge_index.shape[1])
         Np, Ec = slot.npad, slot.ecap
@@ -356,6 +365,11 @@ class StepGraphs:
             segs += [(ei.data_ptr(), sb.edge_index.data_ptr(), E * 8, E * 8, 0),
                      (ei.data_ptr() + E * 8, sb.edge_index.data_ptr() + Ec * 8, E * 8, E * 8, 0),
                      (batch.prob.contiguous(), sb.prob, E * 4, E * 4, 0)]
+            M = 0
+            if slot.canon is not None:
+                canon, mate = src["pairs"]
+                M = int(canon.numel())
+                segs += [(canon, slot.canon, M * 4, M * 4, 0), (mate, slot.mate, E * 4, E * 4, 0)]
         else:
             nm, sn = src["norm"], slot.norm
             segs += [(nm.what_in, sn.what_in, E * 4, E * 4, 0),
@@ -369,7 +383,7 @@ class StepGraphs:
             keep.append((s_, d_))
             words += [sp, dp, nb_s, nb_d, pad]
         arr = (ctypes.c_int64 * len(words))(*words)
-        dims = (ctypes.c_int64 * 1)(E)
+        dims = (ctypes.c_int64 * 2)(E, M if slot.sampled else 0)
         hit = self.stage_cache[key] = (arr, len(segs), dims, keep)
         return hit
 
@@ -377,7 +391,7 @@ class StepGraphs:
         """The partition's arrays -> the slot's static buffers, on the current stream (one launch)."""
         arr, n, dims, _ = self._stage_desc(batch, slot)
         L = _lib.lib()
-        _lib.check(L.sgs_stage_segments(arr, n, slot.dims.data_ptr(), dims, 1, ops._stream()), "sgs_stage_segments")
+        _lib.check(L.sgs_stage_segments(arr, n, slot.dims.data_ptr(), dims, 2, ops._stream()), "sgs_stage_segments")
         slot.live, slot.staged, slot.pre_epoch = batch, None, None      # (`live` also keeps the partition's tensors alive: its key stays unique)
 
     def _pick(self, sampled: bool, like, avoid=None) -> _Slot:

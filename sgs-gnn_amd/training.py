@@ -326,6 +326,8 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
             global_gate = bool(getattr(args, "sgs_dp_global_gate", False))
             esync = sync if not fused_dp else None            # the eager collectives below are for every other case
             sampled = h.sampled if h is not None else batch.edge_index.shape[1] > q
+            if sampled and h is None:
+                ops.get_pairs(batch.edge_index, batch.x.shape[0], build=True)      # once per partition (cached): mates for the paired scorer forward
             if sampled:
                 st = sampled_forward(pipeline, args, model, batch, q, use_checkpoint, noise) if h is None else None
                 temperature = max(args.t_min, args.t_init - epoch * ((args.t_init - args.t_min) / max_epoch))   # returned, never used by the sampler

@@ -122,6 +122,48 @@ def test_production_size_forward_and_active_backward_vs_fp64_oracle(ops, p):
             assert _rel(a.grad, b.grad) < 2e-5, (name, _rel(a.grad, b.grad))
 
 
+@pytest.mark.parametrize("H,p", [(256, 0.3), (128, 0.0)])
+def test_paired_forward_equals_plain_forward_bitwise(ops, H, p):
+    """sgs_edge_score_fwd_paired (only the canonical edge of every (s -> d), (d -> s) pair runs the H x H contraction; both scores
+    are finished from one set of accumulators) against sgs_edge_score_fwd on the same inputs: bit-identical p for every edge, on
+    an undirected graph stored both ways with extras that must stay unmated or pair off one to one -- self loops, one-directional
+    edges, duplicate edges -- and through autograd (the backward does not depend on which forward ran)."""
+    import sgs_gnn_amd as S
+    N = 700
+    b = S.synthetic_graph(N, 90_000, 8, 3, seed=4, device=DEV)                    # symmetric, coalesced, row-sorted
+    g = torch.Generator().manual_seed(8)
+    extra = torch.randint(0, N, (2, 3000), generator=g)                             # one-directional edges (some duplicate existing ones)
+    loops = torch.arange(0, 50).repeat(2, 1)
+    dup = b.edge_index[:, :500].cpu()                                               # exact duplicates of mated edges
+    ei = torch.cat([b.edge_index.cpu(), extra, loops, dup], dim=1)
+    ei = ei[:, torch.argsort(ei[0] * N + ei[1], stable=True)].contiguous().to(DEV)
+    E = ei.shape[1]
+    codes, _, W1, b1, W2, b2, _ = _case(N, H, 10, 5)
+    canon, mate = ops.get_pairs(ei, N, build=True)
+    m = mate[:E].long().cpu()
+    ar = torch.arange(E)
+    paired = m >= 0
+    assert torch.equal(m[m[paired]], ar[paired])                                    # an involution on the mated edges
+    assert torch.equal(ei.cpu()[:, m[paired]], ei.cpu()[:, paired].flip(0))         # ... onto the reverse edge
+    assert int(paired.sum()) >= b.edge_index.shape[1] and not bool(paired[(ei[0] == ei[1]).cpu()].any())
+    assert canon.numel() == E - int(paired.sum()) // 2
+    seed, site = 31, 2
+    outs = []
+    for pr in (None, (canon, mate)):
+        dl = [t.clone().to(DEV).requires_grad_(True) for t in (codes, W1, b1, W2, b2)]
+        pd = ops.edge_score(dl[0], dl[1], dl[2], dl[3], dl[4], ei, p=p, seed=seed, site=site, pairs=pr)
+        pd.sum().backward()
+        outs.append((pd.detach().clone(), [t.grad.clone() for t in dl]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for ga, gb in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(ga, gb)
+    # and against the oracle, as every other forward variant
+    keep = ops.dropout_keep(seed, site, E, H, p, DEV).cpu() if p > 0 else None
+    eic = ei.cpu()
+    po = O.edge_score(codes[eic[0]].double(), codes[eic[1]].double(), W1.double(), b1.double(), W2.double(), b2.double(), p, keep).squeeze(1)
+    assert float((outs[1][0].cpu().double() - po).abs().max()) < 2e-6
+
+
 def test_scorer_tail_and_probability_range(ops):
     N, H, E = 1013, 256, 100001          # E not a multiple of the 128-edge tile
     codes, ei, W1, b1, W2, b2, _ = _case(N, H, E, 3)

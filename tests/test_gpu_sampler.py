@@ -135,6 +135,18 @@ def test_in_kernel_noise_matches_exported_noise_and_is_exponential(ops):
     # sampling frequency follows the weights: heavier edges are selected more often
     sel_p = float(p[a.mask].mean())
     assert sel_p > float(p.mean())
+    # the small-noise tail (the race's winners) is finely resolved: all 32 random bits feed -log1p(-v).  Among 4 M draws the ~800
+    # values below 2e-4 are all distinct (a 23-bit uniform would put them on ~1700 grid points: collisions certain)
+    big = ops.exp_noise(99, 1, 4_000_000, DEV)
+    small = big[big < 2e-4]
+    assert 500 < small.numel() < 1200 and torch.unique(small).numel() == small.numel() and float(big.min()) > 0 and float(big.max()) <= 16.7
+    # fewer positive weights than q: torch.multinomial raises; the fused draw reports it through stats (threshold key 0)
+    pz = torch.zeros(1000, device=DEV)
+    pz[:10] = 0.5
+    rz = ops.sample_topq(ops.SAMPLE_LEARNED, pz, None, 0.0, 50, ei[:, :1000].contiguous(), seed=1, stream_id=1)
+    with pytest.raises(RuntimeError, match="invalid multinomial"):
+        rz.check()
+    a.check()
 
 
 def test_straight_through_weights_fwd_bwd(ops):

@@ -21,10 +21,10 @@ def _args(**kw):
     return a
 
 
-def _setup(S, p_drop, seed=3, capturable=False):
+def _setup(S, p_drop, seed=3, capturable=False, hid=32):
     torch.manual_seed(seed)
     S.fix_seeds(seed)
-    m = S.GNNModel(24, 32, 5, dropout_prob=p_drop, edge_mlp_type="GCN").to(DEV)
+    m = S.GNNModel(24, hid, 5, dropout_prob=p_drop, edge_mlp_type="GCN").to(DEV)
     kw = dict(capturable=True, fused=True) if capturable else {}
     og = torch.optim.Adam([p for n, p in m.named_parameters() if "gcn" in n], lr=1e-2, **kw)
     oe = torch.optim.Adam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-2, **kw)
@@ -150,7 +150,7 @@ def test_sampled_replay_matches_eager_recomputation_from_its_own_draws(pipeline)
         for p in m.parameters():
             p.grad = None
         c = next(s_ for s_ in sg.slots[True] if s_.live is b)
-        assert c.ecap >= E and c.ecap % 2048 == 0 and int(c.dims.item()) == E
+        assert c.ecap >= E and c.ecap % 2048 == 0 and int(c.dims[0]) == E
         seen = []
         for it in range(3):
             sg.replay_g1(c)
@@ -176,8 +176,13 @@ def test_sampled_replay_matches_eager_recomputation_from_its_own_draws(pipeline)
         sg.release()
 
 
-@pytest.mark.parametrize("pipeline", ["hybrid", "straight_through"])
-def test_one_capture_serves_partitions_of_different_sizes(pipeline):
+@pytest.mark.parametrize("pipeline,hid,shapes,q", [
+    ("hybrid", 32, [(150, 6100), (90, 2600), (120, 4000), (110, 900), (140, 1500), (100, 700)], 1000),
+    ("straight_through", 32, [(150, 6100), (90, 2600), (120, 4000), (110, 900), (140, 1500), (100, 700)], 1000),
+    # H = 128 and > 65 536 candidate edges: the PAIRED bf16x6 scorer forward inside the capture, its live number of canonical
+    # edges read from the slot's second dims word
+    ("hybrid", 128, [(420, 90_000), (380, 70_000), (400, 80_000), (300, 9_000)], 15_000)])
+def test_one_capture_serves_partitions_of_different_sizes(pipeline, hid, shapes, q):
     """The step is captured ONCE per slot, over static buffers sized for the largest partition; a partition is handed over by one
     staging launch and the kernels over the candidate edges read the live edge count from the slot.  Partitions with different
     numbers of nodes (padded with isolated, unlabelled nodes) and edges -- visited in an order that leaves the leftovers of a
@@ -186,10 +191,8 @@ def test_one_capture_serves_partitions_of_different_sizes(pipeline):
     from sgs_gnn_amd.stepgraph import StepGraphs
     from sgs_gnn_amd.training import _ce
     crit = torch.nn.CrossEntropyLoss()
-    shapes = [(150, 6100), (90, 2600), (120, 4000), (110, 900), (140, 1500), (100, 700)]
     bs = [S.synthetic_graph(n, E, 24, 5, seed=40 + i, device=DEV) for i, (n, E) in enumerate(shapes)]
-    q = 1000
-    m, og, oe = _setup(S, 0.0)
+    m, og, oe = _setup(S, 0.0, hid=hid)
     a = _args(pipeline=pipeline)
     sg = StepGraphs.attach(m, pipeline, a, crit, q, False, loader=bs)
     sg.debug_keep = True
@@ -200,7 +203,9 @@ def test_one_capture_serves_partitions_of_different_sizes(pipeline):
                 E, N = b.edge_index.shape[1], b.x.shape[0]
                 h = sg.forward(b)
                 c = h.c
-                assert c.live is b and int(c.dims.item()) == E and c.npad == 150
+                assert c.live is b and int(c.dims[0]) == E and c.npad == max(n_ for n_, _ in shapes)
+                if h.sampled and hid == 128:
+                    assert c.canon is not None and E // 2 <= int(c.dims[1]) < E          # the paired forward ran, half the edges canonical
                 if h.sampled:
                     cnt = h.gate_counts()
                     k = _kept(c, b)
@@ -229,7 +234,12 @@ def test_one_capture_serves_partitions_of_different_sizes(pipeline):
                             assert torch.allclose(p.grad, got[i], rtol=2e-4, atol=2e-6), i
                 for p in params:
                     p.grad = None
-        assert sg.captures == 4                        # two slots per kind, captured on their first use, nothing afterwards
+        # two slots per kind, captured on their first use, nothing afterwards (the third list has ONE unsampled partition, which
+        # stays live in its slot: the second unsampled slot is never needed)
+        assert sg.captures == (4 if hid == 32 else 3)
+        if hid == 128:
+            # and in eager mode the same model takes the paired forward as well (the recomputation above went through it)
+            assert S.ops.get_pairs(bs[0].edge_index, bs[0].x.shape[0]) is not None
     finally:
         sg.release()
 
