@@ -97,19 +97,22 @@ def _pmc_traffic(E):
     """HBM bytes per launch of the scorer forward from the separate rocprofv3 --pmc passes on this very kernel and shape
     (profiles/r0*_scorer_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction applied); None if the resident shape
     differs from the profiled one."""
-    for name in ("r02_scorer_pmc.json", "r01_scorer_pmc.json"):
+    names = ("r02_scorer_paired_pmc.json",) if E < 0 else ("r02_scorer_pmc.json", "r01_scorer_pmc.json")      # E < 0: the paired entry point
+    for name in names:
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if f"E={E}," in pmc["kernel"]:
+            if f"E={abs(E)}," in pmc["kernel"]:
                 return pmc["hbm_traffic_bytes_per_launch"]
         except Exception:
             pass
     return None
 
 
-def kernel_roofline(S, model, batch, reps, n_nodes=N_NODES, hid=HID):
+def kernel_roofline(S, model, batch, reps, n_nodes=N_NODES, hid=HID, paired=False):
     """Live HIP-event timing of the dominant kernel (the fused MFMA edge scorer, forward over all E
-    candidate edges of a partition) on the stream it is launched on (torch's current stream)."""
+    candidate edges of a partition) on the stream it is launched on (torch's current stream).
+    `paired`: the entry point the training step uses on an undirected graph stored both ways (sgs_edge_score_fwd_paired: the
+    canonical edge of every (s -> d), (d -> s) pair runs the contraction, both scores come out of its epilogue)."""
     ops = S.ops
     E = batch.edge_index.shape[1]
     H = hid
@@ -121,35 +124,62 @@ def kernel_roofline(S, model, batch, reps, n_nodes=N_NODES, hid=HID):
     ws = ops.workspace(L.sgs_edge_score_workspace_bytes(n_nodes, H, E), codes.device)
     W1, b1, w2, b2 = sc.fc1.weight.detach().contiguous(), sc.fc1.bias.detach(), sc.fc2.weight.detach().reshape(-1).contiguous(), sc.fc2.bias.detach()
 
+    M = E
+    if paired:
+        canon, mate = ops.get_pairs(batch.edge_index, n_nodes, build=True)
+        M = int(canon.numel())
+
     def launch():
-        S._lib.check(L.sgs_edge_score_fwd(codes.data_ptr(), U.data_ptr(), n_nodes, H, batch.edge_index.data_ptr(), E, 0, W1.data_ptr(),
-                                          b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), 0.3, 1, 2, out.data_ptr(), ws.data_ptr(),
-                                          ws.numel(), torch.cuda.current_stream().cuda_stream), "edge_score_fwd")
+        if paired:
+            S._lib.check(L.sgs_edge_score_fwd_paired(codes.data_ptr(), U.data_ptr(), n_nodes, H, batch.edge_index.data_ptr(), E, 0, canon.data_ptr(), M,
+                                                     mate.data_ptr(), W1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), 0.3, 1, 2, out.data_ptr(),
+                                                     ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), "edge_score_fwd_paired")
+        else:
+            S._lib.check(L.sgs_edge_score_fwd(codes.data_ptr(), U.data_ptr(), n_nodes, H, batch.edge_index.data_ptr(), E, 0, W1.data_ptr(),
+                                              b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), 0.3, 1, 2, out.data_ptr(), ws.data_ptr(),
+                                              ws.numel(), torch.cuda.current_stream().cuda_stream), "edge_score_fwd")
     ms = _hip_time(launch, reps)
-    flops = E * (2.0 * H * H + 2.0 * H)          # algorithmic flops per launch after the W1 split
+    flops = E * (2.0 * H * H + 2.0 * H)          # algorithmic flops per launch after the W1 split: per CANDIDATE edge
+    executed = M * 2.0 * H * H + E * 2.0 * H     # what the launch actually issues (the H x H contraction for the M canonical edges only)
     achieved = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": "sgs_edge_score_fwd", "achieved": round(achieved, 3),
             "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": _pmc_traffic(E), "edges_per_launch": E, "ms_per_launch": round(ms, 4),
-            "flops_per_edge": 2 * H * H + 2 * H}
+            "traffic": _pmc_traffic(E) if not paired else _pmc_traffic(-E), "edges_per_launch": E, "canonical_edges_per_launch": M,
+            "ms_per_launch": round(ms, 4), "flops_per_edge": 2 * H * H + 2 * H,
+            "executed_tflops": round(executed / (ms * 1e-3) / 1e12, 3)}
 
 
 def scorer_roofline(S, model, big, score_variant, n_nodes=N_NODES, hid=HID, alts=True):
     L = S._lib.lib()
     names = {0: "lds_tiled", 1: "stream_32_edge_wave_tile", 2: "weight_stationary_persistent", 3: "stream_64_edge_wave_tile",
-             4: "bf16x6_split_on_bf16_mfma"}
+             4: "bf16x6_split_on_bf16_mfma", 5: "bf16x6_paired"}
     auto = 4 if hid % 128 == 0 else 3
     used = score_variant if score_variant >= 0 else auto           # automatic choice at this E (>= 65 536 edges)
+    paired = score_variant < 0 and bool(L.sgs_edge_score_paired_supported(hid))      # what the steps run on an undirected graph (ops.edge_score)
     alt = {}
     if alts:
         for v, name in names.items():                                  # in-process A/B of the scorer forward kernels
-            if v == used:
+            if v == 5 or (v == used and not paired):
                 continue
             L.sgs_edge_score_set_variant(v)
             r_ = kernel_roofline(S, model, big, reps=20, n_nodes=n_nodes, hid=hid)
             alt[name] = {"achieved": r_["achieved"], "ms_per_launch": r_["ms_per_launch"]}
     L.sgs_edge_score_set_variant(score_variant)
-    roof = kernel_roofline(S, model, big, reps=20, n_nodes=n_nodes, hid=hid)       # the variant used by the timed steps
+    roof = kernel_roofline(S, model, big, reps=20, n_nodes=n_nodes, hid=hid, paired=paired)       # the entry point the timed steps use
+    if paired:
+        used = 5
+        roof["kernel"] = "sgs_edge_score_fwd_paired (bf16x6 loop, MODE 3: canonical edges run the contraction, mates ride along)"
+        roof["peak"] = round(BF16X6_PEAK_TFLOPS, 1)
+        roof["frac"] = round(roof["achieved"] / BF16X6_PEAK_TFLOPS, 4)
+        roof["peak_note"] = ("achieved = ALGORITHMIC fp32 flops (2 H^2 + 2 H per CANDIDATE edge, SURVEY.md 8d) / time; peak = dense bf16 MFMA peak 2500 / 6 "
+                             "(six bf16 MFMA products per fp32 product, exact 3-way splits).  The launch ISSUES the H x H contraction only for the "
+                             "canonical edge of every (s->d, d->s) pair -- `executed_tflops`, `executed_frac` price that work")
+        roof["executed_frac"] = round(roof["executed_tflops"] / BF16X6_PEAK_TFLOPS, 4)
+        roof["bf16_mfma_tflops_executed"] = round(6 * roof["executed_tflops"], 1)
+        roof["vs_fp32_mfma_peak"] = round(roof["achieved"] / F32_MFMA_PEAK_TFLOPS, 4)
+        if alts:
+            roof["alt_variants"] = alt
+        return roof
     roof["kernel"] = f"sgs_edge_score_fwd, forward variant {used} ({names[used]})"
     if used == 4:
         roof["peak"] = round(BF16X6_PEAK_TFLOPS, 1)
@@ -342,7 +372,7 @@ def run_s3(a, S, rank, world, device):
             rec["branch_ms"]["note"] = "one step per train() call, synchronised: includes the per-call host overhead, no prefetch overlap"
         rec["hbm_reserved_GiB"] = round(torch.cuda.memory_reserved() / 2**30, 2)
         big = max(pool, key=lambda b: b.edge_index.shape[1])
-        rec["roofline"] = scorer_roofline(S, model, big, a.score_variant)
+        rec["roofline"] = scorer_roofline(S, model, big, a.score_variant, alts=bool(a.alts))
         if not a.no_cpu_baseline:
             above = [b for b in pool if b.edge_index.shape[1] > Q]
             cpu_b = min(above, key=lambda b: b.edge_index.shape[1]) if above else big      # smallest sampled partition: bounded CPU time
@@ -474,6 +504,7 @@ def main():
     ap.add_argument("--diag-steps", type=int, default=48, help="S3, one GPU: synchronised single steps for the per-branch times")
     ap.add_argument("--pool", type=int, default=None, help="(deprecated alias of --parts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--alts", type=int, default=1, help="1 (default): also time the other scorer forward kernels in-process (roofline.alt_variants); 0: skip")
     ap.add_argument("--fused-adam", type=int, default=1, help="1 (default): sgs_gnn_amd.FusedAdam (one launch per group, captured with the step); 0: torch.optim.Adam (foreach, eager)")
     ap.add_argument("--score-variant", type=int, default=-1, help="scorer forward kernel for the timed steps (benchmarking A/B; -1 = library default)")
     ap.add_argument("--hipgraph", type=int, default=1, help="1 (default): every step replayed from the HIP graphs captured once over static "

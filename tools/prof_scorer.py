@@ -15,8 +15,16 @@ codes = torch.relu(torch.randn(N, H, device=dev, generator=g))
 ei = torch.randint(0, N, (2, E), device=dev, generator=g)
 fc1 = torch.nn.Linear(2 * H, H).to(dev)
 fc2 = torch.nn.Linear(H, 1).to(dev)
+pairs = None
+if len(sys.argv) > 3 and sys.argv[3] == "paired":
+    # the paired entry point on the bench stream's largest partition (an undirected graph stored both ways): `E` is ignored
+    sizes = S.reddit_partition_sizes(230, seed=1000, q=100_000)
+    idx = max(range(len(sizes)), key=lambda i: sizes[i])
+    ei = S.reddit_partition_stream(num_parts=230, seed=1000, nfeat=602, ncls=41, n=N, q=100_000, device=dev, only={idx})[idx].edge_index
+    pairs = S.ops.get_pairs(ei, N, build=True)
+    print("paired: E", ei.shape[1], "canonical", pairs[0].numel())
 with torch.no_grad():
     for _ in range(reps):
-        p = S.ops.edge_score(codes, fc1.weight, fc1.bias, fc2.weight, fc2.bias, ei, p=0.3, seed=1, site=2)
+        p = S.ops.edge_score(codes, fc1.weight, fc1.bias, fc2.weight, fc2.bias, ei, p=0.3, seed=1, site=2, pairs=pairs)
 torch.cuda.synchronize()
 print("ok", float(p.mean()))

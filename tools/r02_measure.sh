@@ -11,15 +11,19 @@ python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_window.json 2> $O/bench_driver_window.err
 python bench.py --hipgraph 0 --fused-adam 0 --no-cpu-baseline --epochs 1 --diag-steps 0 > $O/bench_eager.json 2> $O/bench_eager.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --epochs 0 --diag-steps 0 > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --epochs 2 --diag-steps 0 --alts 0 > $O/stats.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- python3 $R/tools/prof_scorer.py $EBIG 6 > $O/pmc_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/tools/prof_scorer.py $EBIG 6 > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/tools/prof_scorer.py $EBIG 6 > $O/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/ppmc_sq -- python3 $R/tools/prof_scorer.py $EBIG 6 paired > $O/ppmc_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/ppmc_fetch -- python3 $R/tools/prof_scorer.py $EBIG 6 paired > $O/ppmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/ppmc_write -- python3 $R/tools/prof_scorer.py $EBIG 6 paired > $O/ppmc_write.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $O/seg -- python3 $R/tools/g1_trace.py > $O/seg.log 2>&1
 cd $R
-python tools/pmc_summary.py $O/pmc_sq $O/pmc_fetch $O/pmc_write edge_score_bf16x6 $O/scorer_pmc.json $EBIG > /dev/null
+python tools/pmc_summary.py $O/pmc_sq $O/pmc_fetch $O/pmc_write "edge_score_bf16x6_kernel<8, 4, 0>" $O/scorer_pmc.json $EBIG > /dev/null
+python tools/pmc_summary.py $O/ppmc_sq $O/ppmc_fetch $O/ppmc_write "edge_score_bf16x6_kernel<8, 4, 3>" $O/scorer_paired_pmc.json $EBIG > /dev/null
 python tools/g1_trace_analyze.py $O/seg > $O/graph_segments_timeline.txt
-grep -v "^[EWI]2026" $O/seg.log | tail -3 > $O/graph_segment_times.txt
+python tools/g1_trace.py 2>/dev/null | tail -3 > $O/graph_segment_times.txt          # HIP-event segment times WITHOUT the profiler attached
 cp $O/stats/*/*kernel_stats.csv $O/bench_kernel_stats_whole_process.csv
 # per-kernel totals of the STEPS only: dispatches from the first staging launch on (everything before it builds the synthetic pool)
 python - <<PY
@@ -42,7 +46,7 @@ for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
 PY
 python - <<PY
 import csv, glob, json
-rows = [r for r in csv.DictReader(open(glob.glob("$O/stats/*/*kernel_trace.csv")[0])) if "edge_score_bf16x6_kernel<8, 4, 0>" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(glob.glob("$O/stats/*/*kernel_trace.csv")[0])) if "edge_score_bf16x6_kernel<8, 4, 3>" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 last = rows[-20:]                      # bench.py's roofline loop: 20 timed launches on the largest partition, issued last
 avg = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last) / len(last) / 1e3
@@ -51,7 +55,7 @@ json.dump({"rocprofv3_kernel_trace_avg_us_last20_bf16x6": round(avg, 1), "bench_
            "edges_per_launch": line["roofline"]["edges_per_launch"],
            "note": "events time sgs_edge_score_fwd = W1a split/pack launch (~5 us) + this kernel"}, open("$O/scorer_agreement.json", "w"), indent=1)
 PY
-for d in pmc_sq pmc_fetch pmc_write; do mkdir -p $O/keep_$d; python - <<PY
+for d in pmc_sq pmc_fetch pmc_write ppmc_sq ppmc_fetch ppmc_write; do mkdir -p $O/keep_$d; python - <<PY
 import csv, glob
 f = glob.glob("$O/$d/*/*counter_collection.csv")[0]
 rows = [r for r in csv.reader(open(f))]
@@ -59,5 +63,5 @@ keep = [rows[0]] + [r for r in rows[1:] if "edge_score" in r[8]]
 csv.writer(open("$O/keep_$d/counter_collection_edge_score.csv", "w")).writerows(keep)
 PY
 done
-rm -rf $O/stats $O/pmc_sq $O/pmc_fetch $O/pmc_write $O/seg
+rm -rf $O/stats $O/pmc_sq $O/pmc_fetch $O/pmc_write $O/ppmc_sq $O/ppmc_fetch $O/ppmc_write $O/seg
 ls -la $O
