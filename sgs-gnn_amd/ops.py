@@ -659,7 +659,7 @@ def edge_score(codes, fc1_w, fc1_b, fc2_w, fc2_b, edge_index, active=None, p=0.0
     get_pairs(edge_index) holds (nothing is built here)."""
     _need_gpu(codes, fc1_w, edge_index)
     if isinstance(pairs, str):
-        pairs = get_pairs(edge_index, codes.shape[0]) if edge_id_offset == 0 else None
+        pairs = get_pairs(edge_index, codes.shape[0])
     return _EdgeScore.apply(codes.contiguous(), fc1_w.contiguous(), fc1_b.contiguous(), fc2_w.reshape(-1).contiguous(), fc2_b.contiguous(),
                             edge_index.contiguous(), active, float(p), int(seed), int(site), int(edge_id_offset), pairs)
 

@@ -62,6 +62,10 @@ class EdgeShard:
         self.edge_index = batch.edge_index[:, lo:hi].contiguous()
         self.prob = batch.prob[lo:hi].contiguous() if getattr(batch, "prob", None) is not None else None
         self.N = batch.x.shape[0]
+        if self.edge_index.is_cuda and self.edge_index.shape[1] >= 65536:
+            # mates INSIDE the shard (a contiguous range of source nodes holds both directions of the edges between its own nodes):
+            # the paired scorer forward halves the contraction work for those, every other edge runs alone -- same p either way
+            ops.get_pairs(self.edge_index, self.N, build=True)
 
 
 def _all_gather_concat(t: torch.Tensor, sizes):
