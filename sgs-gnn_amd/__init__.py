@@ -3,6 +3,7 @@ Python interface.  The numeric work lives in libsgs_hip.so (csrc/*.hip, C ABI in
 include/sgs_hip.h); this package is the host-side mirror of the reference's call sites
 (model.py, sampling.py, training*.py, utils.py).  No CPU fallback exists."""
 from . import _lib, ops  # noqa: F401
+from . import torch_ops  # noqa: F401  (registers torch.ops.sgs.*)
 from .model import GCNConv, GNNModel, GATConv, GAT, GATModel, GINConv, GIN, GINModel, ChebConv, ChebModel, set_dropout_seed  # noqa: F401
 from .scorer import EdgeProbGCN, EdgeProbMLP, EdgeProbSAGE, SAGEConv, get_edge_mlp  # noqa: F401
 from .sampling import gumbel_softmax_sampling, random_edge_sampling, manual_seed  # noqa: F401
