@@ -217,6 +217,10 @@ int sgs_gcn_norm_from_degree(const float* w, const float* degsum, int64_t n_edge
                              float* what_out, float* what_loop, sgs_stream_t stream);
 int sgs_bias_act(const float* X, const float* bias, int64_t N, int64_t D, int act, float p_drop, uint64_t seed,
                  uint32_t site, float* Y, sgs_stream_t stream);
+/* The same on a BLOCK of rows of a larger matrix (node-block sharding): X, Y [n_rows, D] hold rows row_offset .. row_offset + n_rows - 1,
+ * and the dropout rows are those global ids, so the mask equals the unsharded one's. */
+int sgs_bias_act_rows(const float* X, const float* bias, int64_t n_rows, int64_t D, int64_t row_offset, int act, float p_drop,
+                      uint64_t seed, uint32_t site, float* Y, sgs_stream_t stream);
 
 /* GraphSAGE mean aggregation for the GSAGE scorer (model.py:47-89, PyG SAGEConv aggr='mean'): per-entry
  * weights 1 / indeg(dst) in both CSR orders, to be used with sgs_spmm_csr (diag = NULL).

@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(kT) dis_from_degree(const float* __restrict__ 
 // Y = act(X + bias) with the same fused ReLU / counter-based dropout as the SpMM epilogue.
 __global__ void __launch_bounds__(kT) bias_act(const float* __restrict__ X, const float* __restrict__ bias, int64_t N, int64_t D, int act,
                                               float drop_scale, uint32_t drop_thresh, uint64_t seed, uint32_t site,
-                                              const uint64_t* __restrict__ epoch, float* __restrict__ Y) {
+                                              const uint64_t* __restrict__ epoch, float* __restrict__ Y, int64_t row_offset) {
     seed = fold_epoch(seed, epoch);
     const int64_t idx = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
     if (idx >= N * D) return;
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(kT) bias_act(const float* __restrict__ X, cons
     float y = X[idx];
     if (bias) y += bias[c];
     if (act != SGS_ACT_NONE) y = fmaxf(y, 0.f);
-    if (act == SGS_ACT_RELU_DROPOUT) y = dropout_keep_at(seed, site, static_cast<uint64_t>(i), c, drop_thresh) ? y * drop_scale : 0.f;
+    if (act == SGS_ACT_RELU_DROPOUT) y = dropout_keep_at(seed, site, static_cast<uint64_t>(row_offset + i), c, drop_thresh) ? y * drop_scale : 0.f;
     Y[idx] = y;
 }
 
@@ -986,6 +986,11 @@ int sgs_gcn_norm_from_degree(const float* w, const float* degsum, int64_t n_edge
 
 int sgs_bias_act(const float* X, const float* bias, int64_t N, int64_t D, int act, float p_drop, uint64_t seed, uint32_t site,
                  float* Y, sgs_stream_t stream_) {
+    return sgs_bias_act_rows(X, bias, N, D, 0, act, p_drop, seed, site, Y, stream_);
+}
+
+int sgs_bias_act_rows(const float* X, const float* bias, int64_t N, int64_t D, int64_t row_offset, int act, float p_drop, uint64_t seed,
+                      uint32_t site, float* Y, sgs_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     SGS_REQUIRE(N >= 0 && D >= 0 && D < (int64_t(1) << 32) && act >= SGS_ACT_NONE && act <= SGS_ACT_RELU_DROPOUT && p_drop >= 0.f &&
                     p_drop < 1.f, SGS_EINVAL, "sgs_bias_act: bad arguments");
@@ -993,7 +998,7 @@ int sgs_bias_act(const float* X, const float* bias, int64_t N, int64_t D, int ac
     SGS_REQUIRE(X && Y, SGS_EINVAL, "sgs_bias_act: null pointer");
     if (act == SGS_ACT_RELU_DROPOUT && p_drop == 0.f) act = SGS_ACT_RELU;
     hipLaunchKernelGGL(bias_act, dim3(cdiv(N * D, kT)), dim3(kT), 0, stream, X, bias, N, D, act, 1.0f / (1.0f - p_drop),
-                       dropout_thresh(p_drop), seed, site, epoch_ptr(), Y);
+                       dropout_thresh(p_drop), seed, site, epoch_ptr(), Y, row_offset);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

@@ -443,3 +443,391 @@ def train_step_sharded(args, model, shard: EdgeShard, optimizer_gnn, optimizer_e
         optimizer_gnn.step()
     return dict(loss=loss.detach(), sample=smp, random=rs, update_edge_mlp=update_edge_mlp, learned_out=learned_out.detach(),
                 counts=counts)
+
+
+# ======================================================================================================
+# NODE-BLOCK variant of the edge-sharded step: half the embedding bytes of the all-reduce form.
+#
+# The edge list is row-sorted, so a contiguous edge shard is the OUT-edges of a contiguous range of source nodes: rank r owns the
+# node block [nb[r], nb[r+1]) (nb[r] = first source of its shard).  A GCN layer then needs X' only for the rank's own source rows,
+# aggregates its edges into a partial [N, D] sum, and the partial sums are REDUCE-SCATTERED into the blocks (forward) -- the bias /
+# activation / dropout epilogue and the next layer's X W^T run on 1 / R of the rows -- while backward ALL-GATHERS the block
+# gradients.  (This is the mirror image of 8e's "dst-range: all-gather forward, reduce-scatter backward"; with a row-sorted list the
+# source side is the contiguous one.  Same volume: (R-1)/R x [N, D] per layer and direction instead of 2 (R-1)/R.)  Full tables are
+# rebuilt only where edges gather by arbitrary endpoint: the node codes for the scorer and the logits for the consistency
+# regulariser (all-gather forward, reduce-scatter backward).  The one source row a shard boundary may split is exchanged as a
+# one-row halo.  Parameter gradients are partial sums on every rank: ONE flat all-reduce at the end of backward.
+# Sampling, scoring, gcn_norm and the losses are the same kernels and collectives as in train_step_sharded.
+# ======================================================================================================
+class NodeBlocks:
+    """nb [R+1]: rank r owns nodes nb[r] .. nb[r+1]-1 and needs the source rows nb[r] .. nb[r+1] (the last one is the halo: the
+    first node of the next non-empty block, whose edges may start in this shard)."""
+
+    def __init__(self, shard: EdgeShard):
+        rank, world = _world()
+        self.rank, self.world, self.N = rank, world, shard.N
+        ei, dev = shard.edge_index, shard.edge_index.device
+        n = ei.shape[1]
+        if n > 1 and not bool((ei[0, 1:] >= ei[0, :-1]).all()):
+            raise RuntimeError("NodeBlocks: the shard's edge list is not sorted by source (ClusterData / ResidentPartitions emit it sorted)")
+        first = ei[0, :1].clone() if n > 0 else torch.full((1,), shard.N, dtype=torch.int64, device=dev)
+        if _comm():
+            firsts = [torch.empty_like(first) for _ in range(world)]
+            dist.all_gather(firsts, first)
+            nb = [int(f) for f in firsts]
+        else:
+            nb = [int(first)]
+        nb[0] = 0
+        for r in range(len(nb) - 2, -1, -1):              # an empty shard owns nothing: its block collapses onto the next one's start
+            nb[r] = min(nb[r], nb[r + 1])
+        nb[0] = 0
+        self.nb = nb + [shard.N]
+        self.lo, self.hi = self.nb[rank], self.nb[rank + 1]
+        size = [self.nb[r + 1] - self.nb[r] for r in range(world)]
+        # owner of node `hi` = the next rank with a non-empty block (a hub whose edges fill whole shards leaves empty blocks between)
+        self.halo_owner = next((r for r in range(rank + 1, world) if size[r] > 0), None) if self.hi < shard.N else None
+        self.halo = 0 if self.halo_owner is None else 1
+        self.halo_users = [r for r in range(rank) if size[rank] > 0 and self.nb[r + 1] == self.lo
+                           and next((k for k in range(r + 1, world) if size[k] > 0), None) == rank]
+        self.maxb = max(size)
+        n_tot = shard.train_mask.sum().to(torch.int32).reshape(1)          # the mask is replicated: every rank counts the same rows
+        self.n_train = n_tot.contiguous()
+
+    @property
+    def rows(self):
+        return self.hi - self.lo
+
+
+def node_blocks(shard: EdgeShard) -> NodeBlocks:
+    """Cached on the shard (one source-sortedness check and one all-gather of the first sources per shard, not per step)."""
+    B = getattr(shard, "_node_blocks", None)
+    if B is None:
+        B = shard._node_blocks = NodeBlocks(shard)
+    return B
+
+
+def _gather_blocks(block: torch.Tensor, B: NodeBlocks) -> torch.Tensor:
+    """[b_r, D] on every rank -> [N, D] (all-gather of padded blocks)."""
+    if not _comm():
+        return block
+    D = block.shape[1]
+    buf = torch.zeros(B.maxb, D, dtype=block.dtype, device=block.device)
+    buf[:block.shape[0]] = block
+    out = [torch.empty_like(buf) for _ in range(B.world)]
+    dist.all_gather(out, buf)
+    return torch.cat([out[r][:B.nb[r + 1] - B.nb[r]] for r in range(B.world)], dim=0)
+
+
+def _reduce_scatter_blocks(full: torch.Tensor, B: NodeBlocks) -> torch.Tensor:
+    """[N, D] partial sums on every rank -> this rank's block of their sum.  RCCL: reduce_scatter of padded blocks; gloo has no
+    reduce_scatter, so the CPU-side tests run all-reduce + slice (same result)."""
+    if not _comm():
+        return full
+    if dist.get_backend() == "nccl":
+        D = full.shape[1]
+        parts = []
+        for r in range(B.world):
+            buf = torch.zeros(B.maxb, D, dtype=full.dtype, device=full.device)
+            buf[:B.nb[r + 1] - B.nb[r]] = full[B.nb[r]:B.nb[r + 1]]
+            parts.append(buf)
+        out = torch.empty_like(parts[0])
+        dist.reduce_scatter(out, parts)
+        return out[:B.rows].contiguous()
+    t = full.clone()
+    dist.all_reduce(t)
+    return t[B.lo:B.hi].contiguous()
+
+
+class _RS(torch.autograd.Function):
+    """partial [N, D] -> this rank's block of the sum; backward: all-gather of the block gradients."""
+
+    @staticmethod
+    def forward(ctx, part, B):
+        ctx.B = B
+        return _reduce_scatter_blocks(part.contiguous(), B)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _gather_blocks(g.contiguous(), ctx.B), None
+
+
+class _AG(torch.autograd.Function):
+    """block -> full [N, D] table for gathers by arbitrary endpoint; backward: reduce-scatter of the (partial) table gradients."""
+
+    @staticmethod
+    def forward(ctx, block, B):
+        ctx.B = B
+        return _gather_blocks(block.contiguous(), B)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _reduce_scatter_blocks(g.contiguous(), ctx.B), None
+
+
+class _Halo(torch.autograd.Function):
+    """block [b, D] -> source rows [b + halo, D]: appends the first row of the next non-empty block; backward returns that row's
+    gradient to its owner.  One [R, D] all-gather each way."""
+
+    @staticmethod
+    def forward(ctx, block, B):
+        ctx.B = B
+        if not _comm():
+            return block
+        D = block.shape[1]
+        first = block[:1].contiguous() if block.shape[0] > 0 else torch.zeros(1, D, dtype=block.dtype, device=block.device)
+        rows = [torch.empty_like(first) for _ in range(B.world)]
+        dist.all_gather(rows, first)
+        return torch.cat([block, rows[B.halo_owner]], dim=0) if B.halo else block
+
+    @staticmethod
+    def backward(ctx, g):
+        B = ctx.B
+        if not _comm():
+            return g, None
+        D = g.shape[1]
+        gb = g[:B.rows].clone()
+        mine = g[B.rows:B.rows + 1].contiguous() if B.halo else torch.zeros(1, D, dtype=g.dtype, device=g.device)
+        rows = [torch.empty_like(mine) for _ in range(B.world)]
+        dist.all_gather(rows, mine)
+        for r in B.halo_users:                           # ranks that used my first row as their halo
+            gb[0] += rows[r][0]
+        return gb, None
+
+
+class _EmbedRows(torch.autograd.Function):
+    """rows [n, D] -> [N, D] with the rows at offset `a`, zeros elsewhere (the SpMM gathers by global source id)."""
+
+    @staticmethod
+    def forward(ctx, rows, a, N):
+        ctx.a, ctx.n = a, rows.shape[0]
+        full = torch.zeros(N, rows.shape[1], dtype=rows.dtype, device=rows.device)
+        full[a:a + rows.shape[0]] = rows
+        return full
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[ctx.a:ctx.a + ctx.n].contiguous(), None, None
+
+
+class _BiasActRows(torch.autograd.Function):
+    """Layer epilogue on a block of rows; dropout rows are global node ids (sgs_bias_act_rows)."""
+
+    @staticmethod
+    def forward(ctx, X, bias, row0, act, p, seed, site):
+        L = _lib.lib()
+        n, D = X.shape
+        Y = torch.empty_like(X)
+        if n > 0:
+            _lib.check(L.sgs_bias_act_rows(ops._ptr(X.contiguous()), ops._ptr(bias), n, D, int(row0), act, float(p), seed, site, ops._ptr(Y),
+                                           ops._stream()), "sgs_bias_act_rows")
+        ctx.act, ctx.p, ctx.has_bias = act, float(p), bias is not None
+        ctx.save_for_backward(Y if act != ops.ACT_NONE else None)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        L = _lib.lib()
+        (Y,) = ctx.saved_tensors
+        dY = dY.contiguous()
+        if ctx.act != ops.ACT_NONE and dY.numel() > 0:
+            dZ = torch.empty_like(dY)
+            _lib.check(L.sgs_act_bwd(ops._ptr(dY), ops._ptr(Y), dY.numel(), ctx.act, ctx.p, ops._ptr(dZ), ops._stream()), "sgs_act_bwd")
+        else:
+            dZ = dY
+        db = None
+        if ctx.has_bias:
+            db = ops._colsum(dZ) if dZ.shape[0] > 0 else torch.zeros(dZ.shape[1], dtype=dZ.dtype, device=dZ.device)
+        return dZ, db, None, None, None, None, None
+
+
+class _BlockCE(torch.autograd.Function):
+    """This block's share of nn.CrossEntropyLoss()(logits[train], y[train]): sum of the block's train-row losses / #train rows of
+    the WHOLE graph, so the ranks' values add up to the replicated loss (training_hybrid.py:113)."""
+
+    @staticmethod
+    def forward(ctx, logits_b, yb, mb_u8, n_train):
+        L = _lib.lib()
+        n, C = logits_b.shape
+        dev = logits_b.device
+        if n == 0:
+            ctx.empty, ctx.C = True, C
+            return torch.zeros((), dtype=torch.float32, device=dev)
+        ctx.empty = False
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        row_lse, rowloss = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+        nb = torch.empty(1, dtype=torch.int32, device=dev)
+        _lib.check(L.sgs_masked_ce_fwd(ops._ptr(logits_b), n, C, ops._ptr(yb), ops._ptr(mb_u8), ops._ptr(loss), ops._ptr(row_lse), ops._ptr(rowloss),
+                                       ops._ptr(nb), ops._stream()), "sgs_masked_ce_fwd")
+        ctx.save_for_backward(logits_b, yb, mb_u8, row_lse, n_train)
+        return rowloss.sum() / n_train[0].to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.empty:                                    # an empty gradient, not None: the layers above hold collectives every rank must enter
+            return torch.zeros(0, ctx.C, dtype=torch.float32, device=g.device), None, None, None
+        L = _lib.lib()
+        logits_b, yb, mb_u8, row_lse, n_train = ctx.saved_tensors
+        n, C = logits_b.shape
+        g = g.reshape(1).contiguous().float()
+        d = torch.empty_like(logits_b)
+        _lib.check(L.sgs_masked_ce_bwd(ops._ptr(logits_b), n, C, ops._ptr(yb), ops._ptr(mb_u8), ops._ptr(row_lse), ops._ptr(n_train), ops._ptr(g),
+                                       ops._ptr(d), ops._stream()), "sgs_masked_ce_bwd")
+        return d, None, None, None
+
+
+class _ShardedNormBlock(torch.autograd.Function):
+    """As _ShardedNorm, with the self-loop term owned (added and differentiated) by the rank that owns the node."""
+
+    @staticmethod
+    def forward(ctx, w, graph, box, lo, hi):
+        nm = sharded_norm(graph, w)
+        keep = torch.zeros_like(nm.what_loop)
+        keep[lo:hi] = 1.0
+        nm.what_loop = nm.what_loop * keep
+        box.append(nm)
+        ctx.nm, ctx.keep = nm, keep
+        return torch.empty(graph.n_edges + graph.N, dtype=torch.float32, device=w.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        nm, gr = ctx.nm, ctx.nm.graph
+        g = g.contiguous()
+        n, N = gr.n_edges, gr.N
+        gw = g[:n].contiguous() if n > 0 else torch.zeros(1, dtype=torch.float32, device=g.device)
+        gl = (g[n:] * ctx.keep).contiguous()
+        Hn = torch.empty(N, dtype=torch.float32, device=g.device)
+        wv = nm.w if n > 0 else torch.zeros(1, dtype=torch.float32, device=g.device)
+        _lib.check(L.sgs_gcn_norm_bwd_node(ops._ptr(wv), ops._ptr(gw), ops._ptr(gl), n, N, ops._ptr(nm.dis), ops._ptr(nm.loopw),
+                                           ops._ptr(gr.in_ptr), ops._ptr(gr.in_src), ops._ptr(gr.in_eid), ops._ptr(gr.out_ptr),
+                                           ops._ptr(gr.out_dst), ops._ptr(gr.out_eid), ops._ptr(Hn), ops._stream()), "sgs_gcn_norm_bwd_node")
+        if _comm():
+            dist.all_reduce(Hn)
+        dw = torch.empty(n, dtype=torch.float32, device=g.device)
+        if n > 0:
+            _lib.check(L.sgs_gcn_norm_bwd_edge(ops._ptr(gw), ops._ptr(gl), n, N, ops._ptr(nm.dis), ops._ptr(gr.loop_eid),
+                                               ops._ptr(gr.edge_index), ops._ptr(Hn), ops._ptr(dw), ops._stream()), "sgs_gcn_norm_bwd_edge")
+        return dw, None, None, None, None
+
+
+def _block_norm(graph, w, B: NodeBlocks):
+    if w is None or not (w.requires_grad and torch.is_grad_enabled()):
+        nm = sharded_norm(graph, None if w is None else w.detach().contiguous())
+        keep = torch.zeros_like(nm.what_loop)
+        keep[B.lo:B.hi] = 1.0
+        nm.what_loop = nm.what_loop * keep
+        return nm
+    box = []
+    handle = _ShardedNormBlock.apply(w.contiguous(), graph, box, B.lo, B.hi)
+    nm = box[0]
+    nm.handle = handle
+    return nm
+
+
+def block_gcn_layer(src_rows, W, bias, nm, B: NodeBlocks, act=ops.ACT_NONE, p=0.0, seed=0, site=0):
+    """One GCN layer in node-block form.  `src_rows` [rows + halo, Fin]: the layer input for this rank's source rows; returns the
+    layer output for this rank's BLOCK [rows, D]."""
+    xl_rows = ops.linear_nobias(src_rows, W)                                # 1 / R of the node-level GEMM; dW is a partial sum
+    xl = _EmbedRows.apply(xl_rows, B.lo, B.N)
+    part = ops._Propagate.apply(xl, nm.handle, None, nm, ops.ACT_NONE, 0.0, 0, 0)      # this rank's edges -> partial [N, D]
+    yb = _RS.apply(part, B)
+    return _BiasActRows.apply(yb, bias, B.lo, act, float(p), int(seed), int(site))
+
+
+def train_step_blocksharded(args, model, shard: EdgeShard, optimizer_gnn, optimizer_edge_prob, criterion, q: int, noise=None):
+    """train_step_sharded with the GCN layers in node-block form (reduce-scatter forward / all-gather backward, node-level work on
+    1 / R of the rows): same draws (bit for bit), same logits and gradients up to fp32 summation order.  Returns the same trace dict;
+    `learned_out` is the full [N, C] table (all-gathered for the regulariser anyway)."""
+    from .model import _DropoutClock
+    from .sampling import _NoiseClock
+    noise = noise or {}
+    model.train()
+    optimizer_edge_prob.zero_grad()
+    optimizer_gnn.zero_grad()
+    sc = model.edge_prob_mlp
+    x, N, ei = shard.x, shard.N, shard.edge_index
+    p = sc.dropout.p
+    act = ops.ACT_RELU_DROPOUT if p > 0 else ops.ACT_RELU
+    off, bounds = shard.edge_offset, shard.bounds
+    B = node_blocks(shard)
+    x_rows = x[B.lo:B.hi + B.halo]
+    yb, mb = shard.y[B.lo:B.hi].contiguous(), shard.train_mask[B.lo:B.hi].contiguous()
+
+    seed_n, tick = (0, 0) if noise.get("prior") is not None else _NoiseClock.next()
+    rs = dist_sample_topq(ops.SAMPLE_PRIOR, shard.prob, None, 0.0, q, ei, off, bounds, noise_local=noise.get("prior"), seed=seed_n,
+                          stream_id=tick)
+    g_r = ops.get_subgraph(ei, N, rs, eid=rs.eid - off)
+    nm_r = _block_norm(g_r, None, B)
+    h = block_gcn_layer(x_rows, sc.gcn1.lin.weight, sc.gcn1.bias, nm_r, B, act=act, p=p, seed=_DropoutClock.next_seed(), site=SITE_ENC)
+    codes_b = block_gcn_layer(_Halo.apply(h, B), sc.gcn2.lin.weight, sc.gcn2.bias, nm_r, B, act=ops.ACT_RELU)
+    codes = _AG.apply(codes_b, B)                                           # the scorer gathers codes by arbitrary endpoint
+    active = ops.ActiveSet()
+    p_local = ops.edge_score(codes, sc.fc1.weight, sc.fc1.bias, sc.fc2.weight, sc.fc2.bias, ei, active=active, p=p,
+                             seed=_DropoutClock.next_seed(), site=SITE_SCORE, edge_id_offset=off)
+    seed_n, tick = (0, 0) if noise.get("sample") is not None else _NoiseClock.next()
+    smp = dist_sample_topq(ops.SAMPLE_LEARNED, p_local, shard.prob, args.degree_bias_coef, q, ei, off, bounds,
+                           noise_local=noise.get("sample"), seed=seed_n, stream_id=tick)
+    local_ids = smp.eid - off
+    g_s = ops.get_subgraph(ei, N, smp, eid=local_ids)
+    active.set(local_ids, g_s)
+    w_local = p_local.index_select(0, local_ids)
+    nm_s = _block_norm(g_s, w_local, B)
+    pg = model.dropout.p
+    actg = ops.ACT_RELU_DROPOUT if pg > 0 else ops.ACT_RELU
+    h1 = block_gcn_layer(x_rows, model.gcn1.lin.weight, model.gcn1.bias, nm_s, B, act=actg, p=pg, seed=_DropoutClock.next_seed(), site=SITE_GNN)
+    out_b = block_gcn_layer(_Halo.apply(h1, B), model.gcn2.lin.weight, model.gcn2.bias, nm_s, B)
+    update_edge_mlp, random_b, counts = True, None, None
+    dev = x.device
+    if args.conditional:
+        h1r = block_gcn_layer(x_rows, model.gcn1.lin.weight, model.gcn1.bias, nm_r, B, act=actg, p=pg, seed=_DropoutClock.next_seed(), site=SITE_GNN)
+        random_b = block_gcn_layer(_Halo.apply(h1r, B), model.gcn2.lin.weight, model.gcn2.bias, nm_r, B)
+        cbuf = torch.zeros(4, dtype=torch.int32, device=dev)
+        if B.rows > 0:
+            ops.masked_correct(out_b, yb, mb, out=cbuf[0:2])
+            ops.masked_correct(random_b, yb, mb, out=cbuf[2:4])
+        if _comm():
+            dist.all_reduce(cbuf)                                           # gate counts: block sums -> global
+        counts = cbuf.tolist()
+        update_edge_mlp = counts[0] > counts[2]
+
+    mb_u8 = ops._u8(mb)
+
+    def block_ce(logits_b):                                                 # the ranks' values sum to the replicated cross entropy
+        return _BlockCE.apply(logits_b.contiguous(), yb, mb_u8, B.n_train)
+
+    learned_out, reg = None, None
+    if update_edge_mlp:
+        ce = block_ce(out_b)
+        loss = ce
+        c1 = args.regularizer1_coef if args.reg1 else 0.0
+        c2 = args.consist_reg_coef if args.reg2 else 0.0
+        learned_out = _AG.apply(out_b, B)                                   # the consistency regulariser gathers logits by endpoint
+        if c1 != 0.0 or c2 != 0.0:
+            reg = _ShardedEdgeReg.apply(w_local.contiguous(), learned_out.contiguous(), smp.edge_index, shard.y, ops._u8(shard.train_mask),
+                                        g_s, float(c1), float(c2), q)
+            loss = ce + reg                        # the global value on every rank; its backward yields this rank's edges' share only
+        loss.backward()
+    else:
+        ce = block_ce(random_b)
+        ce.backward()
+    # every parameter gradient is a partial sum: ONE flat all-reduce
+    if _comm():                                    # (every rank built the same autograd graph, so the same parameters hold gradients)
+        params = [p_ for p_ in model.parameters() if p_.grad is not None]
+        flat = torch.cat([p_.grad.reshape(-1) for p_ in params])
+        dist.all_reduce(flat)
+        o = 0
+        for p_ in params:
+            n_ = p_.numel()
+            p_.grad.copy_(flat[o:o + n_].view_as(p_))
+            o += n_
+    total = ce.detach().clone()
+    if _comm():
+        dist.all_reduce(total)
+    if reg is not None:
+        total = total + reg.detach()
+    if update_edge_mlp:
+        optimizer_edge_prob.step()
+    optimizer_gnn.step()
+    if learned_out is None:
+        learned_out = _gather_blocks(out_b.detach(), B)
+    return dict(loss=total, sample=smp, random=rs, update_edge_mlp=update_edge_mlp, learned_out=learned_out.detach(), counts=counts)

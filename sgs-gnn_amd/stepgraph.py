@@ -384,6 +384,10 @@ class StepGraphs:
             words += [sp, dp, nb_s, nb_d, pad]
         arr = (ctypes.c_int64 * len(words))(*words)
         dims = (ctypes.c_int64 * 2)(E, M if slot.sampled else 0)
+        if len(self.stage_cache) >= 8192:
+            # a loader that produces fresh batch objects every epoch must not pin them all: the entries keep their sources alive
+            for k in list(self.stage_cache)[:4096]:
+                del self.stage_cache[k]
         hit = self.stage_cache[key] = (arr, len(segs), dims, keep)
         return hit
 

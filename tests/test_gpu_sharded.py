@@ -236,7 +236,7 @@ def _train_setup():
     return S, b, m, og, oe, args
 
 
-def _sharded_train_worker(rank, world, port, q_out):
+def _sharded_train_worker(rank, world, port, q_out, blocks=False):
     import sys
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -251,7 +251,8 @@ def _sharded_train_worker(rank, world, port, q_out):
         S.fix_seeds(5)
         out = {}
         for step in range(2):
-            tr = sh.train_step_sharded(args, m, shard, og, oe, torch.nn.CrossEntropyLoss(), q)
+            step_fn = sh.train_step_blocksharded if blocks else sh.train_step_sharded
+            tr = step_fn(args, m, shard, og, oe, torch.nn.CrossEntropyLoss(), q)
             if step == 0:
                 out["grads"] = {k: (v.grad.detach().cpu().numpy() if v.grad is not None else None) for k, v in m.named_parameters()}
                 out["mask"] = tr["sample"].mask.cpu().numpy()
@@ -265,10 +266,12 @@ def _sharded_train_worker(rank, world, port, q_out):
         dist.destroy_process_group()
 
 
-def test_sharded_training_step_matches_single_gpu_train():
+@pytest.mark.parametrize("blocks", [False, True])
+def test_sharded_training_step_matches_single_gpu_train(blocks):
     """Config 5 training: f/g operators at the shard boundaries give every rank the complete gradients; the
     2- and 3-rank steps reproduce the regular single-GPU train() (same seeds: noise and dropout are keyed
-    by global ids) and the replicas are bit-identical to each other."""
+    by global ids) and the replicas are bit-identical to each other.  blocks=True: the node-block form (reduce-scatter forward /
+    all-gather backward, node-level work on 1 / R of the rows, one flat parameter-gradient all-reduce) against the same reference."""
     import contextlib
     import io
     S, b, m, og, oe, args = _train_setup()
@@ -290,7 +293,7 @@ def test_sharded_training_step_matches_single_gpu_train():
         ctx = mp.get_context("spawn")
         qq = ctx.Queue()
         port = _free_port()
-        procs = [ctx.Process(target=_sharded_train_worker, args=(r, world, port, qq)) for r in range(world)]
+        procs = [ctx.Process(target=_sharded_train_worker, args=(r, world, port, qq, blocks)) for r in range(world)]
         for p in procs:
             p.start()
         got = dict(qq.get(timeout=300) for _ in range(world))
