@@ -340,7 +340,7 @@ def _s5_setup(path=None):
     return S, b, m, og, oe, args
 
 
-def _s5_worker(rank, world, port, q_out, path):
+def _s5_worker(rank, world, port, q_out, path, blocks=False):
     import sys
     import numpy as np
     sys.path.insert(0, ROOT)
@@ -355,7 +355,7 @@ def _s5_worker(rank, world, port, q_out, path):
         q = b.edge_index.shape[1] // 5
         del b
         S.fix_seeds(5)
-        tr = sh.train_step_sharded(args, m, shard, og, oe, torch.nn.CrossEntropyLoss(), q)
+        tr = (sh.train_step_blocksharded if blocks else sh.train_step_sharded)(args, m, shard, og, oe, torch.nn.CrossEntropyLoss(), q)
         out = dict(mask=np.packbits(tr["sample"].mask.cpu().numpy()), rmask=np.packbits(tr["random"].mask.cpu().numpy()),
                    n_local=int(shard.edge_index.shape[1]), loss=float(tr["loss"]), upd=bool(tr["update_edge_mlp"]))
         if rank == 0:
@@ -366,8 +366,10 @@ def _s5_worker(rank, world, port, q_out, path):
         dist.destroy_process_group()
 
 
-def test_s5_full_reddit_scale_edge_sharded_step_matches_single_gpu():
-    """BASELINE.json config 5 at its size: one hybrid training step on the full-Reddit-sized graph, edge-partitioned over two
+@pytest.mark.parametrize("blocks", [False, True])
+def test_s5_full_reddit_scale_edge_sharded_step_matches_single_gpu(blocks):
+    """(blocks=True: the node-block form of the step -- reduce-scatter forward / all-gather backward -- to the same bounds.)
+    BASELINE.json config 5 at its size: one hybrid training step on the full-Reddit-sized graph, edge-partitioned over two
     ranks (gloo, both on this one MI355X; the embedding all-reduces move 238 MB each), against the single-GPU train() on the
     same graph: both draws select the same 22.9 M edges bit for bit (global exponential race over the shards), same gate,
     logits within 1e-4, gradients within 2e-3 of each tensor's largest entry.
@@ -385,12 +387,12 @@ def test_s5_full_reddit_scale_edge_sharded_step_matches_single_gpu():
     path = f"/dev/shm/sgs_s5_{os.getpid()}.pt"
     torch.save({k: getattr(b, k).cpu() for k in ("x", "edge_index", "y", "train_mask", "val_mask", "test_mask", "prob")}, path)
     try:
-        _s5_compare(S, b, m, og, oe, args, E, q, path)
+        _s5_compare(S, b, m, og, oe, args, E, q, path, blocks)
     finally:
         os.remove(path)
 
 
-def _s5_compare(S, b, m, og, oe, args, E, q, path):
+def _s5_compare(S, b, m, og, oe, args, E, q, path, blocks=False):
     import contextlib
     import io
     import numpy as np
@@ -409,7 +411,7 @@ def _s5_compare(S, b, m, og, oe, args, E, q, path):
     ctx = mp.get_context("spawn")
     qq = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_s5_worker, args=(r, world, port, qq, path)) for r in range(world)]
+    procs = [ctx.Process(target=_s5_worker, args=(r, world, port, qq, path, blocks)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(qq.get(timeout=900) for _ in range(world))
@@ -475,6 +477,11 @@ def _rccl_worker(port, q_out):
         S.fix_seeds(5)
         tr = sh.train_step_sharded(args2, m2, shard, og2, oe2, torch.nn.CrossEntropyLoss(), b.edge_index.shape[1] // 5)
         out["sharded"] = dict(loss=float(tr["loss"]), mask=tr["sample"].mask.cpu().numpy(), logits=tr["learned_out"].cpu().numpy())
+        # (iii) the node-block form: RCCL reduce_scatter / all_gather of padded blocks, halo exchange, flat gradient all-reduce
+        S3, b3, m3, og3, oe3, args3 = _train_setup()
+        S.fix_seeds(5)
+        tr = sh.train_step_blocksharded(args3, m3, sh.EdgeShard(b3, 0, 1), og3, oe3, torch.nn.CrossEntropyLoss(), b3.edge_index.shape[1] // 5)
+        out["blocks"] = dict(loss=float(tr["loss"]), mask=tr["sample"].mask.cpu().numpy(), logits=tr["learned_out"].cpu().numpy())
         q_out.put(out)
     finally:
         dist.destroy_process_group()
@@ -503,3 +510,6 @@ def test_rccl_backend_runs_the_data_parallel_and_the_sharded_step():
         S.train(args, 0, 10, m, og, oe, None, torch.nn.CrossEntropyLoss(), [b], q=b.edge_index.shape[1] // 5)
     assert torch.equal(torch.from_numpy(out["sharded"]["mask"]), tr["sample"].mask.cpu())
     torch.testing.assert_close(torch.from_numpy(out["sharded"]["logits"]), tr["learned_out"].cpu(), rtol=1e-4, atol=1e-5)
+    assert torch.equal(torch.from_numpy(out["blocks"]["mask"]), tr["sample"].mask.cpu())
+    torch.testing.assert_close(torch.from_numpy(out["blocks"]["logits"]), tr["learned_out"].cpu(), rtol=1e-4, atol=1e-5)
+    assert abs(out["blocks"]["loss"] - out["sharded"]["loss"]) < 2e-5
