@@ -285,6 +285,10 @@ int sgs_sddmm_csr(const float* A, const float* B, int64_t N, int64_t D, int64_t 
 int sgs_act_bwd(const float* dY, const float* Y, int64_t n, int act, float p_drop, float* dZ, sgs_stream_t stream);
 size_t sgs_colsum_workspace_bytes(int64_t N, int64_t D);
 int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, void* ws, size_t ws_bytes, sgs_stream_t stream);
+/* Both in one pass (one launch for partition-sized N): dZ = dY * act'(Y) written, colsum[d] = sum_i dZ[i,d] -- the activation and bias
+ * gradients of one layer's backward (autograd of model.py:159-161).  ws: sgs_colsum_workspace_bytes(N, D). */
+int sgs_act_bwd_colsum(const float* dY, const float* Y, int64_t N, int64_t D, int act, float p_drop, float* dZ, float* colsum, void* ws,
+                       size_t ws_bytes, sgs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K1b: fused edge scorer (model.py:29-34 / 115-122 `_edge_score`; never materialises the

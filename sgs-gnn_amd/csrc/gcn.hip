@@ -778,6 +778,38 @@ __global__ void __launch_bounds__(RG * 64) colsum_final(const float* __restrict_
     }
 }
 
+// Partition-sized inputs (N <= kColSmallRows rows): the column sums in ONE launch -- a workgroup owns 16 columns, its 64 row lanes
+// stride the rows and meet in LDS in a fixed tree (deterministic).  ACT: the activation backward rides along, dZ = dY * act'(Y) is
+// written and summed in the same pass (a layer's backward then holds one launch where it held act_bwd + the two colsum stages).
+constexpr int kColSmallRows = 2048;
+template <bool ACT>
+__global__ void __launch_bounds__(1024) colsum_small(const float* __restrict__ A, const float* __restrict__ Y, int64_t N, int64_t D, int act,
+                                                    float drop_scale, float* __restrict__ dZ, float* __restrict__ out) {
+    __shared__ float red[64][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * 16 + cl;
+    float acc = 0.f;
+    if (c < D) {
+#pragma unroll 16
+        for (int64_t r = rl; r < N; r += 64) {        // (N ~ 1 000: all 16 loads of a thread in flight at once)
+            float g = A[r * D + c];
+            if (ACT) {
+                if (act != SGS_ACT_NONE) g = (Y[r * D + c] > 0.f) ? (act == SGS_ACT_RELU_DROPOUT ? g * drop_scale : g) : 0.f;
+                dZ[r * D + c] = g;
+            }
+            acc += g;
+        }
+    }
+    red[rl][cl] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int h = 32; h >= 1; h >>= 1) {
+        if (rl < h) red[rl][cl] += red[rl + h][cl];
+        __syncthreads();
+    }
+    if (rl == 0 && c < D && out) out[c] = red[0][cl];
+}
+
 inline int pick_lpr(int64_t D, int vec) {
     const int64_t need = (D + vec - 1) / vec;
     int lpr = 1;
@@ -1157,8 +1189,14 @@ int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, void* ws, size_
     if (D == 0) return SGS_OK;
     SGS_REQUIRE(out && (N == 0 || A), SGS_EINVAL, "sgs_colsum: null pointer");
     SGS_REQUIRE(ws && ws_bytes >= sgs_colsum_workspace_bytes(N, D), SGS_EWORKSPACE, "sgs_colsum: workspace too small");
-    // (a single-launch form for N <= 2048 -- 16 waves per 64 columns, each thread walking N/16 rows -- measured slower than
-    //  these two launches: +12 us per backward; the serial row walk is not hidden at this size)
+    if (N > 0 && N <= kColSmallRows) {
+        // (round 1 tried a single launch with 64-column workgroups, N/16 rows per thread: slower than the two stages by 12 us per
+        //  backward; with 16-column workgroups a thread walks N/64 rows and all of its loads are in flight together)
+        hipLaunchKernelGGL(colsum_small<false>, dim3(cdiv(D, 16)), dim3(1024), 0, stream, A, static_cast<const float*>(nullptr), N, D, SGS_ACT_NONE, 1.f,
+                           static_cast<float*>(nullptr), out);
+        SGS_LAUNCH_OK();
+        return SGS_OK;
+    }
     Carver cv(ws);
     const int rows = colsum_rows(N);
     const int64_t nchunk = cdiv(N, rows);
@@ -1169,6 +1207,22 @@ int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, void* ws, size_
     else             hipLaunchKernelGGL(colsum_final<4>, dim3(cdiv(D, 64)), dim3(kT), 0, stream, part, nchunk, D, out);
     SGS_LAUNCH_OK();
     return SGS_OK;
+}
+
+
+int sgs_act_bwd_colsum(const float* dY, const float* Y, int64_t N, int64_t D, int act, float p_drop, float* dZ, float* colsum, void* ws,
+                       size_t ws_bytes, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && D >= 0 && p_drop >= 0.f && p_drop < 1.f, SGS_EINVAL, "sgs_act_bwd_colsum: bad arguments");
+    if (D == 0) return SGS_OK;
+    SGS_REQUIRE(dZ && colsum && (N == 0 || (dY && (act == SGS_ACT_NONE || Y))), SGS_EINVAL, "sgs_act_bwd_colsum: null pointer");
+    if (N > 0 && N <= kColSmallRows) {
+        hipLaunchKernelGGL(colsum_small<true>, dim3(cdiv(D, 16)), dim3(1024), 0, stream, dY, Y, N, D, act, 1.0f / (1.0f - p_drop), dZ, colsum);
+        SGS_LAUNCH_OK();
+        return SGS_OK;
+    }
+    if (int rc = sgs_act_bwd(dY, Y, N * D, act, p_drop, dZ, stream_)) return rc;
+    return sgs_colsum(dZ, N, D, colsum, ws, ws_bytes, stream_);
 }
 
 }  // extern "C"

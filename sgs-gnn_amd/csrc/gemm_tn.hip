@@ -52,6 +52,61 @@ __global__ void __launch_bounds__(64) gemm_tn_tile(const float* __restrict__ A, 
     }
 }
 
+// Partition-sized K (K = ~1 000 graph nodes, 2 .. 8 K-slices): the slices of one 32 x 32 output tile are the NW waves of ONE
+// workgroup, their partial tiles meet in LDS in a fixed tree and wave 0 writes C (row stride ldc) -- no slab round trip through
+// HBM and no reduction launch (a step of the learned branch holds eight of these products; each second launch cost ~5 us).
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) gemm_tn_wg(const float* __restrict__ A, const float* __restrict__ B, int64_t K, int M, int N,
+                                                     float* __restrict__ C, int64_t ldc) {
+    __shared__ float red[NW / 2][16][64];
+    const int lane = threadIdx.x & 63, s = threadIdx.x >> 6, kh = lane >> 5, l31 = lane & 31;
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    const int i = ti * 32 + l31, j = tj * 32 + l31;
+    const bool iok = i < M, jok = j < N;
+    const int64_t per = ((K + NW - 1) / NW + 1) & ~int64_t(1);              // even slice length, as gemm_tn_tile with ksplit = NW
+    const int64_t k0 = s * per, k1 = (k0 + per < K) ? k0 + per : K;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    int64_t k = k0;
+    for (; k + 2 * kUnroll <= k1; k += 2 * kUnroll) {
+        float a[kUnroll], b[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t kk = k + 2 * u + kh;
+            a[u] = iok ? A[kk * M + i] : 0.f;
+            b[u] = jok ? B[kk * N + j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    }
+    for (; k < k1; k += 2) {
+        const int64_t kk = k + kh;
+        const float a = (iok && kk < k1) ? A[kk * M + i] : 0.f;
+        const float b = (jok && kk < k1) ? B[kk * N + j] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int half = NW / 2; half >= 1; half >>= 1) {                       // upper half stores, lower half adds, halve, repeat
+        if (s >= half && s < 2 * half) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[s - half][r][lane] = acc[r];
+        }
+        __syncthreads();
+        if (s < half) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += red[s][r][lane];
+        }
+        __syncthreads();
+    }
+    if (s != 0 || !jok) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < M) C[static_cast<int64_t>(row) * ldc + j] = acc[r];
+    }
+}
+
 // `N`, `ldc`: C is written with row stride ldc (>= N): the result may be a column block of a wider matrix (fc1.weight's halves)
 __global__ void __launch_bounds__(256) gemm_tn_reduce(const float* __restrict__ slab, int64_t mn, int ksplit, float* __restrict__ C,
                                                       const float* __restrict__ cpart = nullptr, int M = 0, float* __restrict__ colsum = nullptr,
@@ -382,7 +437,16 @@ static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, in
     else if (use_tall(K, M, N))
         hipLaunchKernelGGL(gemm_tn_tall_tile, dim3(cdiv(M, 128), cdiv(N, 64), ks), dim3(64), 0, stream, A, B, K, static_cast<int>(M),
                            static_cast<int>(N), ks, dst, colsum_A ? cpart : static_cast<float*>(nullptr));
-    else
+    else if (ks == 2 || ks == 4 || ks == 8) {
+        // partition-sized K: the K-slices are the waves of one workgroup, reduced in LDS, C written in place (any ldc)
+        const dim3 grid(cdiv(M, 32), cdiv(N, 32));
+        const int64_t ld = ldc > 0 ? ldc : N;
+        if (ks == 8)      hipLaunchKernelGGL((gemm_tn_wg<8>), grid, dim3(512), 0, stream, A, B, K, static_cast<int>(M), static_cast<int>(N), C, ld);
+        else if (ks == 4) hipLaunchKernelGGL((gemm_tn_wg<4>), grid, dim3(256), 0, stream, A, B, K, static_cast<int>(M), static_cast<int>(N), C, ld);
+        else              hipLaunchKernelGGL((gemm_tn_wg<2>), grid, dim3(128), 0, stream, A, B, K, static_cast<int>(M), static_cast<int>(N), C, ld);
+        SGS_LAUNCH_OK();
+        return SGS_OK;
+    } else
         hipLaunchKernelGGL(gemm_tn_tile, dim3(cdiv(M, 32), cdiv(N, 32), ks), dim3(64), 0, stream, A, B, K, static_cast<int>(M),
                            static_cast<int>(N), ks, dst);
     if (ks > 1 || strided)

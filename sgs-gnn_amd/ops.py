@@ -491,12 +491,15 @@ class _Propagate(torch.autograd.Function):
         X, Y = ctx.saved_tensors
         N, D = X.shape
         dY = dY.contiguous()
-        if ctx.act != ACT_NONE:
+        dX = dbias = g = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.act != ACT_NONE and want_db:
+            dZ, dbias = _act_bwd_colsum(dY, Y, ctx.act, ctx.p)
+        elif ctx.act != ACT_NONE:
             dZ = torch.empty_like(dY)
             _lib.check(L.sgs_act_bwd(_ptr(dY), _ptr(Y), dY.numel(), ctx.act, float(ctx.p), _ptr(dZ), _stream()), "sgs_act_bwd")
         else:
             dZ = dY
-        dX = dbias = g = None
         if ctx.needs_input_grad[0]:
             dX = _spmm(dZ, gr.out_ptr, gr.out_dst, nm.what_out, nm.what_loop, None, ACT_NONE, 0.0, 0, 0, N, D, gr.n_edges)
         if ctx.has_handle and ctx.needs_input_grad[1]:
@@ -504,7 +507,7 @@ class _Propagate(torch.autograd.Function):
             gw, gl = g[:gr.n_edges], g[gr.n_edges:]
             _lib.check(L.sgs_sddmm_csr(_ptr(dZ), _ptr(X), N, D, gr.n_edges, _ptr(gr.in_ptr), _ptr(gr.in_src), _ptr(gr.in_eid),
                                        gw.data_ptr(), gl.data_ptr(), _stream()), "sgs_sddmm_csr")
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if want_db and dbias is None:
             dbias = _colsum(dZ)
         return dX, g, dbias, None, None, None, None, None
 
@@ -530,6 +533,18 @@ class ActiveSet:
 
     def set(self, eid: torch.Tensor, graph: Graph):
         self.eid, self.graph = eid, graph
+
+
+def _act_bwd_colsum(dY, Y, act, p):
+    """(dZ, colsum(dZ)) with dZ = dY * act'(Y): the activation and bias gradients of a layer in one pass."""
+    L = _lib.lib()
+    N, D = dY.shape
+    dZ = torch.empty_like(dY)
+    out = torch.empty(D, dtype=torch.float32, device=dY.device)
+    ws = workspace(L.sgs_colsum_workspace_bytes(N, D), dY.device)
+    _lib.check(L.sgs_act_bwd_colsum(_ptr(dY), _ptr(Y), N, D, act, float(p), _ptr(dZ), _ptr(out), ws.data_ptr(), ws.numel(), _stream()),
+               "sgs_act_bwd_colsum")
+    return dZ, out
 
 
 def _colsum(A):
@@ -826,12 +841,15 @@ class _GATAggregate(torch.autograd.Function):
         dev = xl.device
         f32 = dict(dtype=torch.float32, device=dev)
         dY = dY.contiguous()
-        if ctx.act != ACT_NONE:
+        dbias = None
+        if ctx.act != ACT_NONE and ctx.has_bias:
+            dZ, dbias = _act_bwd_colsum(dY, Y, ctx.act, ctx.p_act)
+        elif ctx.act != ACT_NONE:
             dZ = torch.empty_like(dY)
             _lib.check(L.sgs_act_bwd(_ptr(dY), _ptr(Y), dY.numel(), ctx.act, ctx.p_act, _ptr(dZ), _stream()), "sgs_act_bwd")
         else:
             dZ = dY
-        dbias = _colsum(dZ) if ctx.has_bias else None
+            dbias = _colsum(dZ) if ctx.has_bias else None
         # alpha re-ordered into src-CSR entry order for the transposed aggregation
         by_eid = torch.empty(max(n, 1), **f32)
         alpha_out = torch.empty(max(n, 1), **f32)
@@ -974,12 +992,15 @@ class _GCNLayer(torch.autograd.Function):
         x, W, xl, Y = ctx.saved_tensors
         N, D = xl.shape
         dY = dY.contiguous()
-        if ctx.act != ACT_NONE:
+        dx = dW = g = dbias = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[3]
+        if ctx.act != ACT_NONE and want_db:
+            dZ, dbias = _act_bwd_colsum(dY, Y, ctx.act, ctx.p)
+        elif ctx.act != ACT_NONE:
             dZ = torch.empty_like(dY)
             _lib.check(L.sgs_act_bwd(_ptr(dY), _ptr(Y), dY.numel(), ctx.act, float(ctx.p), _ptr(dZ), _stream()), "sgs_act_bwd")
         else:
             dZ = dY
-        dx = dW = g = dbias = None
         need_x, need_W = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if need_x or need_W:
             dxl = _spmm(dZ, gr.out_ptr, gr.out_dst, nm.what_out, nm.what_loop, None, ACT_NONE, 0.0, 0, 0, N, D, gr.n_edges)
@@ -996,7 +1017,7 @@ class _GCNLayer(torch.autograd.Function):
             gw, gl = g[:gr.n_edges], g[gr.n_edges:]
             _lib.check(L.sgs_sddmm_csr(_ptr(dZ), _ptr(xl), N, D, gr.n_edges, _ptr(gr.in_ptr), _ptr(gr.in_src), _ptr(gr.in_eid),
                                        gw.data_ptr(), gl.data_ptr(), _stream()), "sgs_sddmm_csr")
-        if ctx.has_bias and ctx.needs_input_grad[3]:
+        if want_db and dbias is None:
             dbias = _colsum(dZ)
         return dx, dW, g, dbias, None, None, None, None, None, None
 
