@@ -409,6 +409,17 @@ int sgs_edge_reg_fwd(const float* w, const int64_t* sampled_edge_index, int64_t 
 int sgs_edge_reg_bwd(const float* w, const int64_t* sampled_edge_index, int64_t q, int64_t q_global, const float* logits,
                      int64_t N, int64_t C, const int64_t* y, const uint8_t* train_mask, const float* out, float coef1,
                      float coef2, const float* grad_loss, float* dw, float* Gs, float* Gd, sgs_stream_t stream);
+
+/* The learned branch's whole loss (training_hybrid.py:105-133: criterion + coef1 reg1 + coef2 reg2) in three launches, for
+ * criterion = nn.CrossEntropyLoss():  out[7] = {reg1, reg2, #valid, sum labels, coef1 reg1 + coef2 reg2, cross entropy, loss};
+ * row_lse[N], rowloss[N], n_rows[1] as sgs_masked_ce_fwd.  Backward: sgs_edge_reg_bwd (reads out[0..4]) -> sgs_endpoint_reduce ->
+ * sgs_masked_ce_bwd_acc, which ADDS the cross entropy's gradient to the dlogits already there. */
+int sgs_hybrid_loss_fwd(const float* logits, int64_t N, int64_t C, const int64_t* y, const uint8_t* train_mask, const float* w,
+                        const int64_t* sampled_edge_index, int64_t q, float coef1, float coef2, float* out, float* row_lse, float* rowloss,
+                        int32_t* n_rows, void* ws, size_t ws_bytes, sgs_stream_t stream);
+int sgs_masked_ce_bwd_acc(const float* logits, int64_t N, int64_t C, const int64_t* y, const uint8_t* train_mask, const float* row_lse,
+                          const int32_t* n_rows, const float* grad_loss, float* dlogits, sgs_stream_t stream);
+
 /* Edge-sharded losses: raw[4] = {sum bce, sum (w-cos)^2, #valid, sum labels} over THIS rank's sampled edges; the
  * ranks all-reduce raw, form reg1 / reg2 with the global q, and call sgs_edge_reg_bwd with out[2], out[3] = the
  * global #valid / label sum and q_global = the global number of sampled edges (q_global = q when unsharded). */

@@ -810,6 +810,59 @@ __global__ void __launch_bounds__(1024) colsum_small(const float* __restrict__ A
     if (rl == 0 && c < D && out) out[c] = red[0][cl];
 }
 
+// D % 4 == 0: the same pass on 16-byte words -- a thread owns four columns and N/256 rows, so every load of a thread is in flight at
+// once and the 16-column row segments stay whole 64-byte reads.
+template <bool ACT>
+__global__ void __launch_bounds__(1024) colsum_small_v4(const float* __restrict__ A, const float* __restrict__ Y, int64_t N, int64_t D, int act,
+                                                       float drop_scale, float* __restrict__ dZ, float* __restrict__ out) {
+    __shared__ float4 red[256][4];
+    const int cg = threadIdx.x & 3, rl = threadIdx.x >> 2;
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * 16 + 4 * cg;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < D) {
+#pragma unroll 8
+        for (int64_t r = rl; r < N; r += 256) {
+            float4 g = *reinterpret_cast<const float4*>(A + r * D + c);
+            if (ACT) {
+                if (act != SGS_ACT_NONE) {
+                    const float4 y = *reinterpret_cast<const float4*>(Y + r * D + c);
+                    const float sc = act == SGS_ACT_RELU_DROPOUT ? drop_scale : 1.f;
+                    g.x = y.x > 0.f ? g.x * sc : 0.f; g.y = y.y > 0.f ? g.y * sc : 0.f;
+                    g.z = y.z > 0.f ? g.z * sc : 0.f; g.w = y.w > 0.f ? g.w * sc : 0.f;
+                }
+                *reinterpret_cast<float4*>(dZ + r * D + c) = g;
+            }
+            acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+        }
+    }
+    red[rl][cg] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int h = 128; h >= 1; h >>= 1) {
+        if (rl < h) {
+            const float4 o = red[rl + h][cg];
+            float4 m = red[rl][cg];
+            m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+            red[rl][cg] = m;
+        }
+        __syncthreads();
+    }
+    if (rl == 0 && c < D && out) *reinterpret_cast<float4*>(out + c) = red[0][cg];
+}
+
+// A vector's sum (D = 1, e.g. d fc2.bias = sum of dz over the q active edges) in one workgroup: the two-stage kernels above would spend
+// a 64-column workgroup on every row chunk of a one-column matrix.
+constexpr int64_t kVecSumMax = int64_t(1) << 20;
+__global__ void __launch_bounds__(1024) vecsum_small(const float* __restrict__ A, int64_t N, float* __restrict__ out) {
+    __shared__ float red[16];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int64_t i = threadIdx.x;
+    for (; i + 3 * 1024 < N; i += 4 * 1024) { a0 += A[i]; a1 += A[i + 1024]; a2 += A[i + 2048]; a3 += A[i + 3072]; }
+    for (; i < N; i += 1024) a0 += A[i];
+    const float r = block_sum((a0 + a1) + (a2 + a3), red);
+    if (threadIdx.x == 0) out[0] = r;
+}
+
 inline int pick_lpr(int64_t D, int vec) {
     const int64_t need = (D + vec - 1) / vec;
     int lpr = 1;
@@ -1192,8 +1245,17 @@ int sgs_colsum(const float* A, int64_t N, int64_t D, float* out, void* ws, size_
     if (N > 0 && N <= kColSmallRows) {
         // (round 1 tried a single launch with 64-column workgroups, N/16 rows per thread: slower than the two stages by 12 us per
         //  backward; with 16-column workgroups a thread walks N/64 rows and all of its loads are in flight together)
-        hipLaunchKernelGGL(colsum_small<false>, dim3(cdiv(D, 16)), dim3(1024), 0, stream, A, static_cast<const float*>(nullptr), N, D, SGS_ACT_NONE, 1.f,
-                           static_cast<float*>(nullptr), out);
+        if (D % 4 == 0)
+            hipLaunchKernelGGL(colsum_small_v4<false>, dim3(cdiv(D, 16)), dim3(1024), 0, stream, A, static_cast<const float*>(nullptr), N, D, SGS_ACT_NONE,
+                               1.f, static_cast<float*>(nullptr), out);
+        else
+            hipLaunchKernelGGL(colsum_small<false>, dim3(cdiv(D, 16)), dim3(1024), 0, stream, A, static_cast<const float*>(nullptr), N, D, SGS_ACT_NONE, 1.f,
+                               static_cast<float*>(nullptr), out);
+        SGS_LAUNCH_OK();
+        return SGS_OK;
+    }
+    if (D == 1 && N > 0 && N <= kVecSumMax) {
+        hipLaunchKernelGGL(vecsum_small, dim3(1), dim3(1024), 0, stream, A, N, out);
         SGS_LAUNCH_OK();
         return SGS_OK;
     }
@@ -1217,7 +1279,8 @@ int sgs_act_bwd_colsum(const float* dY, const float* Y, int64_t N, int64_t D, in
     if (D == 0) return SGS_OK;
     SGS_REQUIRE(dZ && colsum && (N == 0 || (dY && (act == SGS_ACT_NONE || Y))), SGS_EINVAL, "sgs_act_bwd_colsum: null pointer");
     if (N > 0 && N <= kColSmallRows) {
-        hipLaunchKernelGGL(colsum_small<true>, dim3(cdiv(D, 16)), dim3(1024), 0, stream, dY, Y, N, D, act, 1.0f / (1.0f - p_drop), dZ, colsum);
+        if (D % 4 == 0) hipLaunchKernelGGL(colsum_small_v4<true>, dim3(cdiv(D, 16)), dim3(1024), 0, stream, dY, Y, N, D, act, 1.0f / (1.0f - p_drop), dZ, colsum);
+        else            hipLaunchKernelGGL(colsum_small<true>, dim3(cdiv(D, 16)), dim3(1024), 0, stream, dY, Y, N, D, act, 1.0f / (1.0f - p_drop), dZ, colsum);
         SGS_LAUNCH_OK();
         return SGS_OK;
     }

@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(64) gemm_tn_tile(const float* __restrict__ A, 
 // Partition-sized K (K = ~1 000 graph nodes, 2 .. 8 K-slices): the slices of one 32 x 32 output tile are the NW waves of ONE
 // workgroup, their partial tiles meet in LDS in a fixed tree and wave 0 writes C (row stride ldc) -- no slab round trip through
 // HBM and no reduction launch (a step of the learned branch holds eight of these products; each second launch cost ~5 us).
+constexpr int kWgUnroll = 8;              // k2-steps in flight per wave (16 measured slower by ~1.5 us per launch)
 template <int NW>
 __global__ void __launch_bounds__(64 * NW) gemm_tn_wg(const float* __restrict__ A, const float* __restrict__ B, int64_t K, int M, int N,
                                                      float* __restrict__ C, int64_t ldc) {
@@ -69,16 +70,16 @@ __global__ void __launch_bounds__(64 * NW) gemm_tn_wg(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     int64_t k = k0;
-    for (; k + 2 * kUnroll <= k1; k += 2 * kUnroll) {
-        float a[kUnroll], b[kUnroll];
+    for (; k + 2 * kWgUnroll <= k1; k += 2 * kWgUnroll) {
+        float a[kWgUnroll], b[kWgUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < kWgUnroll; ++u) {
             const int64_t kk = k + 2 * u + kh;
             a[u] = iok ? A[kk * M + i] : 0.f;
             b[u] = jok ? B[kk * N + j] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+        for (int u = 0; u < kWgUnroll; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
     }
     for (; k < k1; k += 2) {
         const int64_t kk = k + kh;

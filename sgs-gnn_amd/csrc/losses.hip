@@ -222,6 +222,44 @@ __global__ void __launch_bounds__(kT) reg_fwd_final(const float* __restrict__ pa
     }
 }
 
+// The learned branch's whole loss in one finishing launch (training_hybrid.py:105-133): the cross entropy's mean over the train rows
+// (as ce_final) and the two regularisers (as reg_fwd_final);  out[0..4] as reg_fwd_final, out[5] = cross entropy,
+// out[6] = out[5] + out[4] = the loss.
+__global__ void __launch_bounds__(kT) hybrid_loss_final(const float* __restrict__ part, int64_t nblk, int64_t q, float coef1, float coef2,
+                                                       const float* __restrict__ rowloss, const uint8_t* __restrict__ mask, int64_t N,
+                                                       float* __restrict__ out, int* __restrict__ n_rows) {
+    __shared__ float red[kT / 64];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, ce = 0.f, cnt = 0.f;
+    for (int64_t b = threadIdx.x; b < nblk; b += kT) {
+        a0 += part[4 * b]; a1 += part[4 * b + 1]; a2 += part[4 * b + 2]; a3 += part[4 * b + 3];
+    }
+    for (int64_t i = threadIdx.x; i < N; i += kT) { ce += rowloss[i]; cnt += mask[i] ? 1.f : 0.f; }     // (counts < 2^24: exact in fp32)
+    const float r0 = block_sum(a0, red), r1 = block_sum(a1, red), r2 = block_sum(a2, red), r3 = block_sum(a3, red);
+    const float rc = block_sum(ce, red), rn = block_sum(cnt, red);
+    if (threadIdx.x == 0) {
+        const float reg1 = (r3 > 1.f) ? r0 / r2 : 0.f;
+        const float reg2 = r1 / static_cast<float>(q);
+        out[0] = reg1; out[1] = reg2; out[2] = r2; out[3] = r3;
+        out[4] = coef1 * reg1 + coef2 * reg2;
+        out[5] = rc / rn;                                  // 0/0 = nan, as torch's mean over an empty selection
+        out[6] = out[5] + out[4];
+        n_rows[0] = static_cast<int>(rn);
+    }
+}
+
+// ce_bwd on top of a gradient that is already there: dlogits += (softmax - onehot) g / #train on the train rows.
+__global__ void __launch_bounds__(kT) ce_bwd_acc(const float* __restrict__ logits, int64_t N, int64_t C, const int64_t* __restrict__ y,
+                                                const uint8_t* __restrict__ mask, const float* __restrict__ row_lse,
+                                                const int* __restrict__ n_rows, const float* __restrict__ grad_loss,
+                                                float* __restrict__ dlogits) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (idx >= N * C) return;
+    const int64_t i = idx / C, c = idx - i * C;
+    if (!mask[i]) return;
+    const float sm = expf(logits[idx] - row_lse[i]);
+    dlogits[idx] += (sm - (y[i] == c ? 1.f : 0.f)) * (grad_loss[0] / static_cast<float>(n_rows[0]));
+}
+
 // raw[0..3] = {sum bce, sum (w-cos)^2, #valid, sum labels} of this rank's edges (edge-sharded losses: the
 // ranks all-reduce these four sums and finish the formulas with the global q).
 __global__ void __launch_bounds__(kT) reg_raw_final(const float* __restrict__ part, int64_t nblk, float* __restrict__ raw) {
@@ -368,6 +406,36 @@ int sgs_edge_reg_fwd(const float* w, const int64_t* sampled_edge_index, int64_t 
     hipLaunchKernelGGL(reg_fwd_partial, dim3(nblk), dim3(kT), 0, stream, w, sampled_edge_index, q, logits, C, y, train_mask, cos_out,
                        part);
     hipLaunchKernelGGL(reg_fwd_final, dim3(1), dim3(kT), 0, stream, part, nblk, q, coef1, coef2, out);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_hybrid_loss_fwd(const float* logits, int64_t N, int64_t C, const int64_t* y, const uint8_t* train_mask, const float* w,
+                        const int64_t* sampled_edge_index, int64_t q, float coef1, float coef2, float* out, float* row_lse, float* rowloss,
+                        int32_t* n_rows, void* ws, size_t ws_bytes, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(q > 0 && N > 0 && N < (int64_t(1) << 24) && C > 0 && logits && y && train_mask && w && sampled_edge_index && out && row_lse &&
+                    rowloss && n_rows,
+                SGS_EINVAL, "sgs_hybrid_loss_fwd: bad arguments");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_reg_workspace_bytes(q), SGS_EWORKSPACE, "sgs_hybrid_loss_fwd: workspace too small");
+    Carver cv(ws);
+    const int64_t nblk = cdiv(q, kT);
+    float* part = cv.take<float>(4 * (nblk + 1));
+    hipLaunchKernelGGL(ce_rows, dim3(cdiv(N * 64, kT)), dim3(kT), 0, stream, logits, N, C, y, train_mask, row_lse, rowloss);
+    hipLaunchKernelGGL(reg_fwd_partial, dim3(nblk), dim3(kT), 0, stream, w, sampled_edge_index, q, logits, C, y, train_mask,
+                       static_cast<float*>(nullptr), part);
+    hipLaunchKernelGGL(hybrid_loss_final, dim3(1), dim3(kT), 0, stream, part, nblk, q, coef1, coef2, rowloss, train_mask, N, out, n_rows);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_masked_ce_bwd_acc(const float* logits, int64_t N, int64_t C, const int64_t* y, const uint8_t* train_mask, const float* row_lse,
+                          const int32_t* n_rows, const float* grad_loss, float* dlogits, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N > 0 && C > 0 && logits && y && train_mask && row_lse && n_rows && grad_loss && dlogits, SGS_EINVAL,
+                "sgs_masked_ce_bwd_acc: bad arguments");
+    hipLaunchKernelGGL(ce_bwd_acc, dim3(cdiv(N * C, kT)), dim3(kT), 0, stream, logits, N, C, y, train_mask, row_lse, n_rows, grad_loss,
+                       dlogits);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

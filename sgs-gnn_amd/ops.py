@@ -809,6 +809,64 @@ def edge_regularizers(w, logits, sampled_edge_index, y, train_mask, coef1, coef2
     return total, box[0]
 
 
+class _HybridLoss(torch.autograd.Function):
+    """criterion + coef1 reg1 + coef2 reg2 as ONE node: three launches forward (row losses, per-edge terms, one finishing block),
+    three backward (per-edge gradients, their endpoint reduction, the cross entropy's gradient added in place) -- as separate nodes
+    the same sum took ten, two of them the adds autograd inserts."""
+
+    @staticmethod
+    def forward(ctx, logits, y, mask_u8, w, sei, graph, coef1, coef2, box):
+        L = _lib.lib()
+        q = w.numel()
+        N, C = logits.shape
+        dev = w.device
+        out = torch.empty(7, dtype=torch.float32, device=dev)
+        row_lse = torch.empty(N, dtype=torch.float32, device=dev)
+        rowloss = torch.empty(N, dtype=torch.float32, device=dev)
+        n_rows = torch.empty(1, dtype=torch.int32, device=dev)
+        ws = workspace(L.sgs_edge_reg_workspace_bytes(q), dev)
+        _lib.check(L.sgs_hybrid_loss_fwd(_ptr(logits), N, C, _ptr(y), _ptr(mask_u8), _ptr(w), _ptr(sei), q, float(coef1), float(coef2), _ptr(out),
+                                         _ptr(row_lse), _ptr(rowloss), _ptr(n_rows), ws.data_ptr(), ws.numel(), _stream()), "sgs_hybrid_loss_fwd")
+        ctx.save_for_backward(logits, y, mask_u8, w, sei, out, row_lse, n_rows)
+        ctx.graph, ctx.coef1, ctx.coef2 = graph, float(coef1), float(coef2)
+        box.append(out)
+        return out[6]
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        logits, y, mask_u8, w, sei, out, row_lse, n_rows = ctx.saved_tensors
+        q = w.numel()
+        N, C = logits.shape
+        dev = w.device
+        g = g.reshape(1).contiguous().float()
+        dw = torch.empty(q, dtype=torch.float32, device=dev)
+        Gs = torch.empty(q, C, dtype=torch.float32, device=dev)
+        Gd = torch.empty(q, C, dtype=torch.float32, device=dev)
+        _lib.check(L.sgs_edge_reg_bwd(_ptr(w), _ptr(sei), q, q, _ptr(logits), N, C, _ptr(y), _ptr(mask_u8), _ptr(out), ctx.coef1,
+                                      ctx.coef2, _ptr(g), _ptr(dw), _ptr(Gs), _ptr(Gd), _stream()), "sgs_edge_reg_bwd")
+        if ctx.coef2 != 0.0:
+            dlogits = _endpoint_reduce(Gs, Gd, None, ctx.graph, 1.0, 1.0, C)
+            _lib.check(L.sgs_masked_ce_bwd_acc(_ptr(logits), N, C, _ptr(y), _ptr(mask_u8), _ptr(row_lse), _ptr(n_rows), _ptr(g), _ptr(dlogits),
+                                               _stream()), "sgs_masked_ce_bwd_acc")
+        else:
+            dlogits = torch.empty_like(logits)
+            _lib.check(L.sgs_masked_ce_bwd(_ptr(logits), N, C, _ptr(y), _ptr(mask_u8), _ptr(row_lse), _ptr(n_rows), _ptr(g), _ptr(dlogits),
+                                           _stream()), "sgs_masked_ce_bwd")
+        return dlogits, None, None, dw, None, None, None, None, None
+
+
+def hybrid_loss(logits, y, train_mask, w, sampled_edge_index, coef1, coef2):
+    """nn.CrossEntropyLoss()(logits[train], y[train]) + coef1 * reg1 + coef2 * reg2 (training_hybrid.py:105-133) as one scalar, plus
+    the detached [reg1, reg2, #valid, sum labels, coef1 reg1 + coef2 reg2, cross entropy, loss] vector."""
+    _need_gpu(w, logits, sampled_edge_index, y, train_mask)
+    graph = get_graph(sampled_edge_index, logits.shape[0])
+    box = []
+    total = _HybridLoss.apply(logits.contiguous(), y.contiguous(), _u8(train_mask), w.contiguous(), sampled_edge_index.contiguous(), graph,
+                              float(coef1), float(coef2), box)
+    return total, box[0]
+
+
 # ------------------------------------------------------------------ GAT attention (K8)
 class _GATAggregate(torch.autograd.Function):
     """out = act( sum_k alpha_k x'[src_k] + alpha_loop x'[i] + bias ), alpha = dropout(softmax(leaky_relu(a_s+a_d)))."""

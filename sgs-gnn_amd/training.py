@@ -134,9 +134,12 @@ def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise
 
 def learned_loss(args, criterion, st: SampledForward, batch):
     """training_hybrid.py:105-133: CE + reg1 (BCE on same-class labels) + reg2 (cosine consistency)."""
-    loss = _ce(criterion, st.learned_out, batch)
     c1 = args.regularizer1_coef if args.reg1 == True else 0.0      # noqa: E712 (as the reference)
     c2 = args.consist_reg_coef if args.reg2 == True else 0.0       # noqa: E712
+    if (c1 != 0.0 or c2 != 0.0) and _fused_ce_ok(criterion):
+        # the three terms as one autograd node (ten launches -> six)
+        return ops.hybrid_loss(st.learned_out, batch.y, batch.train_mask, st.edge_probs_for_loss, st.sampled_edge_index, c1, c2)[0]
+    loss = _ce(criterion, st.learned_out, batch)
     if c1 != 0.0 or c2 != 0.0:
         reg, _ = ops.edge_regularizers(st.edge_probs_for_loss, st.learned_out, st.sampled_edge_index, batch.y,
                                        batch.train_mask, c1, c2)
