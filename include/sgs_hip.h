@@ -357,6 +357,33 @@ int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64
 int sgs_edge_score_bwd_dfeat_supported(int64_t H);
 int sgs_edge_score_bwd_dfeat(const float* dv, int64_t n, int64_t H, const float* W1, float* dfeat, void* ws, size_t ws_bytes,
                              sgs_stream_t stream);
+
+/* The MASK form of the scorer backward (H = 128 or 256; sgs_edge_score_bwd_bits_supported).  With v the fc1 pre-activation,
+ *   dv[r, h] = dz[r] * w2[h] * [dropout(relu(v))[r, h] > 0] / (1 - p)            (autograd of model.py:31-33 / 119-121)
+ * is a 0 / 1 matrix times a row and a column factor, so the core writes ONE BIT per entry -- dvbits [n, H/32], bit h of row r in word
+ * h / 32 -- instead of the fp32 [n, H] matrix, and the three consumers take bits + dz + w2:
+ *   sgs_edge_score_bwd_dfeat_bits   dfeat = dv W1a            = dz[r] * (bits[r, :] . diag(w2 / (1 - p)) W1a)
+ *   sgs_gemm_tn_mask                d W1a = dv^T feat, d b1   = diag(w2 / (1 - p)) (bits^T (diag(dz) feat))
+ *   sgs_endpoint_reduce_pair_bits   d U[v] = w2 / (1 - p) * (sum_out - sum_in) dz[e] bits[e, :]   (+ the d codes half, as sgs_endpoint_reduce_pair)
+ * A 0 / 1 operand is exact in bf16: the two contractions issue 3 bf16 MFMA products per fp32 product (the other operand's exact 3-way
+ * split) instead of 6, still fp32-faithful.  Other arguments as sgs_edge_score_bwd_core / _bwd_dfeat / sgs_endpoint_reduce_pair. */
+int sgs_edge_score_bwd_bits_supported(int64_t H);
+int sgs_edge_score_bwd_core_bits(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
+                                 int64_t edge_id_offset, const int64_t* active_eid, int64_t n_active, const float* grad_p, const float* W1,
+                                 const float* b1, const float* w2, const float* b2, float p_drop, uint64_t seed, uint32_t site,
+                                 uint32_t* dvbits, float* hdz_part, float* dz, float* feat, void* ws, size_t ws_bytes, sgs_stream_t stream);
+int sgs_edge_score_bwd_dfeat_bits(const uint32_t* dvbits, const float* dz, int64_t n, int64_t H, const float* W1, const float* w2, float p_drop,
+                                  float* dfeat, void* ws, size_t ws_bytes, sgs_stream_t stream);
+int sgs_endpoint_reduce_pair_bits(const float* dfeat, const uint32_t* dvbits, const float* dz, const float* w2, float p_drop, const float* codes,
+                                  int64_t N, int64_t H, int64_t nnz, const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid,
+                                  const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid, float* out_codes, float* out_U,
+                                  sgs_stream_t stream);
+/* C[M, N] (row stride ldc) = (diag(dz) mask diag(rowscale * scale))^T B, mask bits [K, M/32]; colsum_A (optional, [M]) = that matrix's column
+ * sums.  Tall-K shapes only (sgs_gemm_tn_mask_supported); ws: sgs_gemm_tn_workspace_bytes(K, M, N). */
+int sgs_gemm_tn_mask_supported(int64_t K, int64_t M, int64_t N);
+int sgs_gemm_tn_mask(const uint32_t* Abits, const float* dz, const float* rowscale, float scale, const float* B, int64_t K, int64_t M, int64_t N,
+                     float* C, int64_t ldc, float* colsum_A, void* ws, size_t ws_bytes, sgs_stream_t stream);
+
 int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, int64_t N, int64_t H, int64_t nnz,
                         const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid, const int32_t* out_ptr,
                         const int32_t* out_dst, const int32_t* out_eid, float sign_out, float sign_in, float* out,

@@ -71,6 +71,9 @@ struct ScoreArgs {
     float* hdz;              // backward: [cdiv(n,64), H] per-tile column sums of dz * dropped hidden (rows sum to dw2)
     float* dz;               // backward: [n]
     float* feat;             // backward: [n,H]  x_s * x_d
+    uint32_t* dvbits;        // backward (MODE 1), optional: [n, H/32] bit h of row r = [dropped hidden h of row r > 0] -- with dz and w2 that IS dv
+    const uint32_t* inbits;  // MODE 4 (dfeat from the mask): [n, H/32]
+    const float* indz;       // MODE 4: [n]
 };
 
 // Workgroup = 64 edges x all HP = 32*NT hidden units; wave (eg, hh) owns edges 32eg..32eg+31 and
@@ -694,8 +697,11 @@ __global__ void __launch_bounds__(kT, 2) edge_score_stream64_kernel(ScoreArgs a,
 //     fp32 of each endpoint's row of the plain node codes (two 16-byte loads per endpoint per chunk, no re-layout), multiplied
 //     and split in registers (52 vector instructions per 48 MFMAs), and the fc2 reduction never leaves the wave.
 // Requires H % 128 == 0.
+// rowscale (TRANSPOSED only): the operand is diag(rowscale * scale) W1a, i.e. entry (k, h) is scaled by rowscale[k] * scale before it is
+// split -- the mask form of dfeat folds fc2's weights and the dropout scale into the matrix (MODE 4).
 template <bool TRANSPOSED = false>      // TRANSPOSED: the pieces of W1a^T (row h of the operand = column h of W1a): the row-GEMM mode's operand
-__global__ void __launch_bounds__(kT) pack_w1a_bf16x3(const float* __restrict__ W1, int H, uint4* __restrict__ Wp16) {
+__global__ void __launch_bounds__(kT) pack_w1a_bf16x3(const float* __restrict__ W1, int H, uint4* __restrict__ Wp16,
+                                                     const float* __restrict__ rowscale = nullptr, float scale = 1.f) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;       // one (kc, t, lane)
     const int NTl = H / 32;
     if (i >= static_cast<int64_t>(H / 16) * NTl * 64) return;
@@ -706,8 +712,9 @@ __global__ void __launch_bounds__(kT) pack_w1a_bf16x3(const float* __restrict__ 
     uint32_t p[3][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        const float w0 = TRANSPOSED ? W1[static_cast<int64_t>(k0 + 2 * m) * 2 * H + h] : W1[static_cast<int64_t>(h) * 2 * H + k0 + 2 * m];
-        const float w1 = TRANSPOSED ? W1[static_cast<int64_t>(k0 + 2 * m + 1) * 2 * H + h] : W1[static_cast<int64_t>(h) * 2 * H + k0 + 2 * m + 1];
+        float w0 = TRANSPOSED ? W1[static_cast<int64_t>(k0 + 2 * m) * 2 * H + h] : W1[static_cast<int64_t>(h) * 2 * H + k0 + 2 * m];
+        float w1 = TRANSPOSED ? W1[static_cast<int64_t>(k0 + 2 * m + 1) * 2 * H + h] : W1[static_cast<int64_t>(h) * 2 * H + k0 + 2 * m + 1];
+        if (TRANSPOSED && rowscale) { w0 *= rowscale[k0 + 2 * m] * scale; w1 *= rowscale[k0 + 2 * m + 1] * scale; }
         split3(w0, w1, p[0][m], p[1][m], p[2][m]);
     }
     uint4* o = Wp16 + (static_cast<int64_t>(kc) * NTl + t) * 3 * 64 + lane;
@@ -738,7 +745,7 @@ __global__ void __launch_bounds__(kT) pack_w1a_bf16x3(const float* __restrict__ 
 // set of accumulators: the same p as MODE 0, bit for bit, at ~0.6 x the time.
 template <int NT, int NW, int MODE = 0>
 __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(ScoreArgs a, const uint4* __restrict__ Wp16) {
-    constexpr bool BWD = MODE == 1, GEMM = MODE == 2, PAIR = MODE == 3;
+    constexpr bool BWD = MODE == 1, GEMMB = MODE == 4, GEMM = MODE == 2 || MODE == 4, PAIR = MODE == 3;
     constexpr int H = 32 * NT;
     constexpr int NPH = H / 16;              // phases: one 16-deep k-chunk each, one barrier per phase
     constexpr int CH = NT * 3 * 64;          // 16-byte words per k-chunk of W1a (all hidden units, three pieces)
@@ -776,7 +783,9 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
 
-    struct Feat { float4 xa, xb, ya, yb; };
+    // MODE 4: the input row is a MASK (bit h of row r); lane (l31, kh) needs bits 16 kc + 8 kh .. + 7 of its row per chunk = byte 2 kc + kh
+    const uint8_t* bp = GEMMB ? reinterpret_cast<const uint8_t*>(a.inbits + (live ? r : 0) * (H / 32)) + kh : nullptr;
+    struct Feat { float4 xa, xb, ya, yb; uint32_t mb; };
     // W staging: global -> registers at the head of a phase, registers -> LDS at its end (lane-linear both ways).
     // (global_load_lds was tried first: next to the ordinary feature loads hipcc 7.2 drains vmcnt(0) before the first ds_read
     //  of every phase, which serialises the prefetch.)  Named registers, not an array: an array indexed inside the lambdas
@@ -792,6 +801,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
         if constexpr (SPT > 3) { w[3 * TH + tid] = s3; w[4 * TH + tid] = s4; w[5 * TH + tid] = s5; }
     };
     auto fload = [&](int kc, Feat& f) {
+        if constexpr (GEMMB) { f.mb = bp[2 * kc]; return; }
         f.xa = xp[4 * kc]; f.xb = xp[4 * kc + 1];
         if (!GEMM) { f.ya = yp[4 * kc]; f.yb = yp[4 * kc + 1]; }
     };
@@ -804,7 +814,13 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
     // one k-chunk: split the (dead afterwards) fp32 features, refill them with chunk `kn_` of the next phase, 6 NT MFMAs
     auto chunk = [&](const uint4* wcur, Feat& f, int kc_, int kn_) {
         u32x4 F1, F2, F3;
-        {
+        if constexpr (GEMMB) {
+            // eight mask bits -> eight bf16 ones / zeros: ONE exact piece, so a chunk is 3 MFMAs per tile (the pieces of the matrix)
+            const uint32_t b = f.mb;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) F1[m] = ((b >> (2 * m)) & 1u ? 0x3F80u : 0u) | ((b >> (2 * m + 1)) & 1u ? 0x3F800000u : 0u);
+            F2 = F1; F3 = F1;
+        } else {
             const float4 pa = GEMM ? f.xa : make_float4(f.xa.x * f.ya.x, f.xa.y * f.ya.y, f.xa.z * f.ya.z, f.xa.w * f.ya.w);
             const float4 pb = GEMM ? f.xb : make_float4(f.xb.x * f.yb.x, f.xb.y * f.yb.y, f.xb.z * f.yb.z, f.xb.w * f.yb.w);
             if (BWD && live) {                       // feat[e, k] = x_s[k] x_d[k], k = 16 kc + 8 kh .. + 7, for the weight gradient
@@ -832,6 +848,11 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
             const bf16x8 w1 = __builtin_bit_cast(bf16x8, w.q1), w2 = __builtin_bit_cast(bf16x8, w.q2), w3 = __builtin_bit_cast(bf16x8, w.q3);
             // smallest terms first
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, f1, acc[t], 0, 0, 0);
+            if constexpr (GEMMB) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, f1, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, f1, acc[t], 0, 0, 0);
+                return;
+            }
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, f2, acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, f3, acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, f1, acc[t], 0, 0, 0);
@@ -864,10 +885,13 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
     }
     if constexpr (GEMM) {                            // out[r, 8 i + 4 kh + j] = accumulator register 4 g4 + j of tile t (i = 4 t + g4)
         if (live) {
+            const float rs = GEMMB ? a.indz[r] : 1.f;        // MODE 4: the row's dz was left out of the mask operand
 #pragma unroll
             for (int i = 0; i < 4 * NT; ++i)
                 *reinterpret_cast<float4*>(a.feat + r * H + 8 * i + 4 * kh) =
-                    make_float4(acc[i >> 2][4 * (i & 3)], acc[i >> 2][4 * (i & 3) + 1], acc[i >> 2][4 * (i & 3) + 2], acc[i >> 2][4 * (i & 3) + 3]);
+                    GEMMB ? make_float4(rs * acc[i >> 2][4 * (i & 3)], rs * acc[i >> 2][4 * (i & 3) + 1], rs * acc[i >> 2][4 * (i & 3) + 2],
+                                        rs * acc[i >> 2][4 * (i & 3) + 3])
+                          : make_float4(acc[i >> 2][4 * (i & 3)], acc[i >> 2][4 * (i & 3) + 1], acc[i >> 2][4 * (i & 3) + 2], acc[i >> 2][4 * (i & 3) + 3]);
         }
         return;
     }
@@ -973,6 +997,11 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
     // a wave holds 32 edges; a row of hdz_part is 64 (sgs_edge_score_bwd_tile()): waves 2m and 2m+1 meet in LDS (the W
     // buffers are free: the main loop ended on a barrier)
     float* hsum = reinterpret_cast<float*>(&wl[0][0]);                            // [NW][H]
+    // dv[r, h] = dz[r] * w2[h] * [hd > 0] * scale: one bit per entry carries it (with dz and w2) -- `dvbits` gets bit h of row r in
+    // word h / 32, and the consumers (MODE 4, gemm_tn's mask operand, the endpoint reduction) never read a [n, H] fp32 dv
+    uint32_t mbits[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) mbits[t] = 0u;
 #pragma unroll
     for (int i = 0; i < 4 * NT; ++i) {
         if (8 * i < Hrt) {                           // always true: one basic block per step (register budget, as above)
@@ -986,8 +1015,9 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
                 const float hd = acc[t][4 * g4 + j];
                 dv4[j] = dzv * w4[j] * (hd > 0.f ? dscale : 0.f);                 // hd > 0 <=> v > 0 and kept
                 hs[j] = dzv * hd;
+                mbits[t] |= (hd > 0.f ? 1u : 0u) << (8 * g4 + 4 * kh + j);       // h & 31 = 8 (i & 3) + 4 kh + j, h >> 5 = i >> 2 = t
             }
-            if (live) *reinterpret_cast<float4*>(a.dv + r * H + hb) = make_float4(dv4[0], dv4[1], dv4[2], dv4[3]);
+            if (live && a.dv) *reinterpret_cast<float4*>(a.dv + r * H + hb) = make_float4(dv4[0], dv4[1], dv4[2], dv4[3]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float sum = hs[j];
@@ -996,6 +1026,15 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
                 hs[j] = sum;
             }
             if (l31 == 0) *reinterpret_cast<float4*>(hsum + wave * H + hb) = make_float4(hs[0], hs[1], hs[2], hs[3]);
+        }
+    }
+    if (a.dvbits) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mbits[t] |= __shfl_xor(mbits[t], 32, 64);    // the two halves (kh) of every byte
+        if (live && kh == 0) {
+            uint4* bo = reinterpret_cast<uint4*>(a.dvbits + r * NT);
+#pragma unroll
+            for (int t = 0; t < NT; t += 4) bo[t >> 2] = make_uint4(mbits[t], mbits[t + 1], mbits[t + 2], mbits[t + 3]);
         }
     }
     __syncthreads();
@@ -1200,24 +1239,29 @@ __global__ void __launch_bounds__(64 * NW) endpoint_reduce_rowblock(const float*
         for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
         if (c0 < H) {
             for (int k0 = wave; k0 < total; k0 += 4 * NW) {
+                // indices first, then every row gather, all unconditional (entries past the row: clamped to its last entry, sign 0) --
+                // under `if (k < total)` each entry's index wait (vmcnt(0)) also waited for the previous entry's rows
                 float m[4][VEC], t[4][VEC], sg[4];
+                int er[4], cr[4];
+                const float* Mp[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int k = k0 + NW * u;
-                    sg[u] = 0.f;
+                    const int kc = k < total ? k : total - 1;
+                    const bool isout = kc < no;
+                    const int idx = isout ? ob + kc : ib + (kc - no);
+                    er[u] = (isout ? out_eid : in_eid)[idx];
+                    if (HAS_T) cr[u] = (isout ? out_dst : in_src)[idx];
+                    Mp[u] = isout ? Mo : Mi;
+                    sg[u] = k < total ? (isout ? sgn_out : sgn_in) : 0.f;
+                }
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) { m[u][j] = 0.f; t[u][j] = 1.f; }
-                    if (k < total) {
-                        const bool isout = k < no;
-                        const int idx = isout ? ob + k : ib + (k - no);
-                        const int er = isout ? out_eid[idx] : in_eid[idx];
-                        const float* M = isout ? Mo : Mi;
-                        sg[u] = isout ? sgn_out : sgn_in;
-                        *reinterpret_cast<V*>(m[u]) = *reinterpret_cast<const V*>(M + static_cast<int64_t>(er) * H + c0);
-                        if (HAS_T) {
-                            const int cr = isout ? out_dst[idx] : in_src[idx];
-                            *reinterpret_cast<V*>(t[u]) = *reinterpret_cast<const V*>(T + static_cast<int64_t>(cr) * H + c0);
-                        }
+                for (int u = 0; u < 4; ++u) {
+                    *reinterpret_cast<V*>(m[u]) = *reinterpret_cast<const V*>(Mp[u] + static_cast<int64_t>(er[u]) * H + c0);
+                    if (HAS_T) *reinterpret_cast<V*>(t[u]) = *reinterpret_cast<const V*>(T + static_cast<int64_t>(cr[u]) * H + c0);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) t[u][j] = 1.f;
                     }
                 }
 #pragma unroll
@@ -1245,14 +1289,18 @@ __global__ void __launch_bounds__(64 * NW) endpoint_reduce_rowblock(const float*
 //   out_U[v,:]     = sum_{k in out-row} dv[e_k,:] - sum_{k in in-row} dv[e_k,:]
 // (U[s] enters the pre-activation with +, U[d] with -).  Same row walk, same fixed summation order as two calls of
 // endpoint_reduce_rowblock; the edge ids / other-endpoint ids are read once and three row gathers are in flight per entry.
-constexpr int kEpU = 2;          // entries in flight per wave (4 measured no faster: the pass is bound by the three row streams, ~3.4 TB/s)
-template <int NW>
+// BITS: the dv rows come as mask bits + dz (see sgs_edge_score_bwd_core_bits): out_U[v, c] = w2[c] * scale * (sum_out - sum_in) dz[e] bit[e, c]
+constexpr int kEpU = 4;          // entries in flight per wave
+template <int NW, bool BITS = false>
 __global__ void __launch_bounds__(64 * NW) endpoint_reduce_pair_rowblock(const float* __restrict__ dfeat, const float* __restrict__ dv,
                                                                         const float* __restrict__ codes, int64_t N, int64_t H,
                                                                         const int* __restrict__ in_ptr, const int* __restrict__ in_src,
                                                                         const int* __restrict__ in_eid, const int* __restrict__ out_ptr,
                                                                         const int* __restrict__ out_dst, const int* __restrict__ out_eid,
-                                                                        float* __restrict__ out_codes, float* __restrict__ out_U) {
+                                                                        float* __restrict__ out_codes, float* __restrict__ out_U,
+                                                                        const uint32_t* __restrict__ bits = nullptr,
+                                                                        const float* __restrict__ dz = nullptr,
+                                                                        const float* __restrict__ w2 = nullptr, float scale = 1.f) {
     __shared__ float part[2][NW][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t v = blockIdx.x;
@@ -1264,31 +1312,49 @@ __global__ void __launch_bounds__(64 * NW) endpoint_reduce_pair_rowblock(const f
         float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
         if (c0 < H) {
             for (int k0 = wave; k0 < total; k0 += kEpU * NW) {      // kEpU entries (3 row gathers each) in flight per wave
-                float m1[kEpU][4], m2[kEpU][4], t[kEpU][4], sg[kEpU];
+                // three phases, every load unconditional (entries past the row are clamped to its last entry and weighted 0): with the
+                // loads under `if (k < total)` the compiler waits for entry u's indices with vmcnt(0), i.e. also for the row gathers of
+                // entry u - 1, and the entries go through memory one after the other
+                int er[kEpU], cr[kEpU];
+                float sg[kEpU], ok[kEpU];
 #pragma unroll
                 for (int u = 0; u < kEpU; ++u) {
                     const int k = k0 + NW * u;
-                    sg[u] = 0.f;
+                    const int kc = k < total ? k : total - 1;
+                    const bool isout = kc < no;
+                    const int idx = isout ? ob + kc : ib + (kc - no);
+                    er[u] = (isout ? out_eid : in_eid)[idx];
+                    cr[u] = (isout ? out_dst : in_src)[idx];
+                    ok[u] = k < total ? 1.f : 0.f;
+                    sg[u] = k < total ? (isout ? 1.f : -1.f) : 0.f;
+                }
+                float m1[kEpU][4], m2[kEpU][4], t[kEpU][4];
+                uint32_t wd[kEpU];
+                float dzr[kEpU];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { m1[u][j] = 0.f; m2[u][j] = 0.f; t[u][j] = 0.f; }
-                    if (k < total) {
-                        const bool isout = k < no;
-                        const int idx = isout ? ob + k : ib + (k - no);
-                        const int er = isout ? out_eid[idx] : in_eid[idx];
-                        const int cr = isout ? out_dst[idx] : in_src[idx];
-                        sg[u] = isout ? 1.f : -1.f;
-                        *reinterpret_cast<float4*>(m1[u]) = *reinterpret_cast<const float4*>(dfeat + static_cast<int64_t>(er) * H + c0);
-                        *reinterpret_cast<float4*>(m2[u]) = *reinterpret_cast<const float4*>(dv + static_cast<int64_t>(er) * H + c0);
-                        *reinterpret_cast<float4*>(t[u]) = *reinterpret_cast<const float4*>(codes + static_cast<int64_t>(cr) * H + c0);
+                for (int u = 0; u < kEpU; ++u) {
+                    *reinterpret_cast<float4*>(m1[u]) = *reinterpret_cast<const float4*>(dfeat + static_cast<int64_t>(er[u]) * H + c0);
+                    *reinterpret_cast<float4*>(t[u]) = *reinterpret_cast<const float4*>(codes + static_cast<int64_t>(cr[u]) * H + c0);
+                    if constexpr (BITS) {
+                        wd[u] = bits[static_cast<int64_t>(er[u]) * (H >> 5) + (c0 >> 5)];
+                        dzr[u] = dz[er[u]];
+                    } else {
+                        *reinterpret_cast<float4*>(m2[u]) = *reinterpret_cast<const float4*>(dv + static_cast<int64_t>(er[u]) * H + c0);
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < kEpU; ++u)
+                for (int u = 0; u < kEpU; ++u) {
+                    if constexpr (BITS) {
+                        const uint32_t w = wd[u] >> (c0 & 31);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) m2[u][j] = (w >> j) & 1u ? dzr[u] : 0.f;
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        a1[j] = fmaf(m1[u][j], t[u][j], a1[j]);
+                        a1[j] = fmaf(ok[u] * m1[u][j], t[u][j], a1[j]);
                         a2[j] = fmaf(sg[u], m2[u][j], a2[j]);
                     }
+                }
             }
         }
 #pragma unroll
@@ -1300,6 +1366,7 @@ __global__ void __launch_bounds__(64 * NW) endpoint_reduce_pair_rowblock(const f
                 float sum = 0.f;
 #pragma unroll
                 for (int g = 0; g < NW; g += 4) sum += (part[which][g][c] + part[which][g + 1][c]) + (part[which][g + 2][c] + part[which][g + 3][c]);
+                if (BITS && which) sum *= w2[cbase + c] * scale;
                 (which ? out_U : out_codes)[v * H + cbase + c] = sum;
             }
         }
@@ -1507,17 +1574,50 @@ int sgs_edge_score_fwd_paired(const float* codes, const float* U, int64_t N, int
 /* Backward core over the active rows: recomputes the hidden layer and writes
  * dv [n,H] = dL/d(fc1 pre-activation), hdz_part [cdiv(n, 64), H] = per-64-edge-tile column sums of dz * hidden,
  * dz [n], feat [n,H] = x_s*x_d. */
+static int bwd_core_impl(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
+                         int64_t edge_id_offset, const int64_t* active_eid, int64_t n_active, const float* grad_p, const float* W1,
+                         const float* b1, const float* w2, const float* b2, float p_drop, uint64_t seed, uint32_t site,
+                         float* dv, uint32_t* dvbits, float* hdz_part, float* dz, float* feat, void* ws, size_t ws_bytes,
+                         sgs_stream_t stream_);
+
 int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
                             int64_t edge_id_offset, const int64_t* active_eid, int64_t n_active, const float* grad_p, const float* W1,
                             const float* b1, const float* w2, const float* b2, float p_drop, uint64_t seed, uint32_t site,
                             float* dv, float* hdz_part, float* dz, float* feat, void* ws, size_t ws_bytes,
                             sgs_stream_t stream_) {
+    SGS_REQUIRE(dv || n_active == 0, SGS_EINVAL, "sgs_edge_score_bwd_core: null pointer");
+    return bwd_core_impl(codes, U, N, H, edge_index, E, edge_id_offset, active_eid, n_active, grad_p, W1, b1, w2, b2, p_drop, seed, site, dv,
+                         nullptr, hdz_part, dz, feat, ws, ws_bytes, stream_);
+}
+
+/* The mask form of the backward (H = 128 or 256): dv[r, h] = dz[r] * w2[h] * [hidden h of row r survived ReLU and dropout] / (1 - p), so the
+ * core writes ONE BIT per entry (dvbits [n, H/32], bit h of row r in word h / 32) instead of the fp32 [n, H] matrix, and the three
+ * consumers rebuild what they need from bits + dz + w2: sgs_edge_score_bwd_dfeat_bits, sgs_gemm_tn_mask, sgs_endpoint_reduce_pair_bits.
+ * A 0 / 1 operand is exact in bf16, so those two contractions issue 3 bf16 MFMA products per fp32 product instead of 6. */
+int sgs_edge_score_bwd_bits_supported(int64_t H) { return (H == 128 || H == 256) ? 1 : 0; }
+
+int sgs_edge_score_bwd_core_bits(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
+                                 int64_t edge_id_offset, const int64_t* active_eid, int64_t n_active, const float* grad_p, const float* W1,
+                                 const float* b1, const float* w2, const float* b2, float p_drop, uint64_t seed, uint32_t site,
+                                 uint32_t* dvbits, float* hdz_part, float* dz, float* feat, void* ws, size_t ws_bytes,
+                                 sgs_stream_t stream_) {
+    SGS_REQUIRE(sgs_edge_score_bwd_bits_supported(H) && N > 0, SGS_EINVAL, "sgs_edge_score_bwd_core_bits: H=%lld unsupported (128 or 256)", (long long)H);
+    SGS_REQUIRE(dvbits || n_active == 0, SGS_EINVAL, "sgs_edge_score_bwd_core_bits: null pointer");
+    return bwd_core_impl(codes, U, N, H, edge_index, E, edge_id_offset, active_eid, n_active, grad_p, W1, b1, w2, b2, p_drop, seed, site, nullptr,
+                         dvbits, hdz_part, dz, feat, ws, ws_bytes, stream_);
+}
+
+static int bwd_core_impl(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
+                         int64_t edge_id_offset, const int64_t* active_eid, int64_t n_active, const float* grad_p, const float* W1,
+                         const float* b1, const float* w2, const float* b2, float p_drop, uint64_t seed, uint32_t site,
+                         float* dv, uint32_t* dvbits, float* hdz_part, float* dz, float* feat, void* ws, size_t ws_bytes,
+                         sgs_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (int rc = check_common("sgs_edge_score_bwd_core", N, H, E, p_drop)) return rc;
     SGS_REQUIRE(n_active >= 0 && (active_eid || n_active == E), SGS_EINVAL,
                 "sgs_edge_score_bwd_core: n_active must equal E when active_eid is NULL");
     if (n_active == 0) return SGS_OK;
-    SGS_REQUIRE(codes && U && edge_index && grad_p && W1 && b1 && w2 && b2 && dv && hdz_part && dz && feat, SGS_EINVAL,
+    SGS_REQUIRE(codes && U && edge_index && grad_p && W1 && b1 && w2 && b2 && (dv || dvbits) && hdz_part && dz && feat, SGS_EINVAL,
                 "sgs_edge_score_bwd_core: null pointer");
     SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_workspace_bytes(N, H, 0), SGS_EWORKSPACE, "sgs_edge_score_bwd_core: workspace too small");
     Carver cv(ws);
@@ -1529,7 +1629,7 @@ int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64
     // in LDS anyway, while the streaming loop has to rebuild row pieces from registers with cross-lane swaps.
     // automatic: the bf16x6 loop once the launch fills the chip (measured, tools/bwd_probe.py: 160 vs 230 us at 100 k active rows,
     // 327 vs 574 at 262 k, 618 vs 1009 at 500 k), the LDS-tiled core below that
-    const int bwd_variant = g_bwd_variant >= 0 ? g_bwd_variant : ((H % 128 == 0 && cdiv(n_active, 128) >= 512) ? 4 : 0);
+    const int bwd_variant = dvbits ? 4 : (g_bwd_variant >= 0 ? g_bwd_variant : ((H % 128 == 0 && cdiv(n_active, 128) >= 512) ? 4 : 0));
     if (bwd_variant == 4 && H % 128 == 0 && N > 0) {
         // the recompute on the bf16x6 loop (forward variant 4): same outputs
         cv.take<float>(0);
@@ -1542,7 +1642,7 @@ int sgs_edge_score_bwd_core(const float* codes, const float* U, int64_t N, int64
         b.row_offset = edge_id_offset;
         b.H = static_cast<int>(H); b.WaT = nullptr; b.b1 = b1; b.w2 = w2; b.b2 = b2;
         b.drop_scale = 1.0f / (1.0f - p_drop); b.drop_thresh = dropout_thresh(p_drop); b.seed = seed; b.epoch = epoch_ptr(); b.site = site;
-        b.use_drop = p_drop > 0.f; b.gp = grad_p; b.dv = dv; b.hdz = hdz_part; b.dz = dz; b.feat = feat;
+        b.use_drop = p_drop > 0.f; b.gp = grad_p; b.dv = dv; b.dvbits = dvbits; b.hdz = hdz_part; b.dz = dz; b.feat = feat;
         const dim3 grid(static_cast<unsigned>(cdiv(n_active, 128))), blk(256);
         if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4, 1>), grid, blk, 0, stream, b, Wp16);
         else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4, 1>), grid, blk, 0, stream, b, Wp16);
@@ -1603,6 +1703,33 @@ int sgs_edge_score_bwd_dfeat(const float* dv, int64_t n, int64_t H, const float*
     return SGS_OK;
 }
 
+/* dfeat [n,H] = dv . W1[:, :H] from the mask form of dv: out[r, :] = dz[r] * (bits[r, :] . diag(w2 / (1 - p)) W1a) -- the 0 / 1 operand
+ * is one exact bf16 piece, the scaled matrix is split three ways: 3 MFMA products per fp32 product. */
+int sgs_edge_score_bwd_dfeat_bits(const uint32_t* dvbits, const float* dz, int64_t n, int64_t H, const float* W1, const float* w2, float p_drop,
+                                  float* dfeat, void* ws, size_t ws_bytes, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(n >= 0 && H > 0 && p_drop >= 0.f && p_drop < 1.f, SGS_EINVAL, "sgs_edge_score_bwd_dfeat_bits: bad arguments");
+    SGS_REQUIRE(sgs_edge_score_bwd_bits_supported(H), SGS_EINVAL, "sgs_edge_score_bwd_dfeat_bits: H=%lld unsupported (128 or 256)", (long long)H);
+    if (n == 0) return SGS_OK;
+    SGS_REQUIRE(dvbits && dz && W1 && w2 && dfeat, SGS_EINVAL, "sgs_edge_score_bwd_dfeat_bits: null pointer");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_workspace_bytes(0, H, 0), SGS_EWORKSPACE, "sgs_edge_score_bwd_dfeat_bits: workspace too small");
+    Carver cv(ws);
+    cv.take<float>(static_cast<size_t>(H) * H);
+    cv.take<float>(0);
+    cv.take<float>(0);
+    cv.take<unsigned int>(64);
+    uint4* Wp16 = cv.take<uint4>(static_cast<size_t>(H) * H * 6 / 16);
+    hipLaunchKernelGGL(pack_w1a_bf16x3<true>, dim3(static_cast<unsigned>(cdiv((H / 16) * (H / 32) * 64, kT))), dim3(kT), 0, stream, W1,
+                       static_cast<int>(H), Wp16, w2, 1.0f / (1.0f - p_drop));
+    ScoreArgs a{};
+    a.inbits = dvbits; a.indz = dz; a.n = n; a.H = static_cast<int>(H); a.feat = dfeat;
+    const dim3 grid(static_cast<unsigned>(cdiv(n, 128))), blk(256);
+    if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4, 4>), grid, blk, 0, stream, a, Wp16);
+    else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4, 4>), grid, blk, 0, stream, a, Wp16);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
 int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, int64_t N, int64_t H, int64_t nnz,
                         const int32_t* in_ptr, const int32_t* in_src,
                         const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
@@ -1657,6 +1784,29 @@ int sgs_endpoint_reduce_pair(const float* dfeat, const float* dv, const float* c
     else
         hipLaunchKernelGGL((endpoint_reduce_pair_rowblock<4>), grid, dim3(256), 0, stream, dfeat, dv, codes, N, H, in_ptr, in_src, in_eid, out_ptr,
                            out_dst, out_eid, out_codes, out_U);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_endpoint_reduce_pair_bits(const float* dfeat, const uint32_t* dvbits, const float* dz, const float* w2, float p_drop, const float* codes,
+                                  int64_t N, int64_t H, int64_t nnz, const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid,
+                                  const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid, float* out_codes, float* out_U,
+                                  sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && H >= 0 && H % 32 == 0 && N <= 65536 && p_drop >= 0.f && p_drop < 1.f, SGS_EINVAL,
+                "sgs_endpoint_reduce_pair_bits: needs H %% 32 == 0 and N <= 65536");
+    if (N == 0 || H == 0) return SGS_OK;
+    SGS_REQUIRE(dfeat && dvbits && dz && w2 && codes && in_ptr && out_ptr && out_codes && out_U, SGS_EINVAL,
+                "sgs_endpoint_reduce_pair_bits: null pointer");
+    const dim3 grid(static_cast<unsigned>(N));
+    const float scale = 1.0f / (1.0f - p_drop);
+    const float* nodv = nullptr;
+    if (nnz >= 64 * N)
+        hipLaunchKernelGGL((endpoint_reduce_pair_rowblock<16, true>), grid, dim3(1024), 0, stream, dfeat, nodv, codes, N, H, in_ptr, in_src, in_eid,
+                           out_ptr, out_dst, out_eid, out_codes, out_U, dvbits, dz, w2, scale);
+    else
+        hipLaunchKernelGGL((endpoint_reduce_pair_rowblock<4, true>), grid, dim3(256), 0, stream, dfeat, nodv, codes, N, H, in_ptr, in_src, in_eid,
+                           out_ptr, out_dst, out_eid, out_codes, out_U, dvbits, dz, w2, scale);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

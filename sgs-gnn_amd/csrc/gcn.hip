@@ -713,6 +713,53 @@ __global__ void __launch_bounds__(64 * NW) sddmm_csr_rowblock(const float* __res
         }
         return acc;
     };
+    if (D <= 64 * VEC) {
+        // the usual case (a row fits one pass of the wave): row i's slice stays in registers, FOUR entries per step with their indices
+        // loaded first and the four row gathers issued together (unconditional: entries past the row are clamped and not stored)
+        const int64_t c0 = static_cast<int64_t>(lane) * VEC;
+        const bool in = c0 < D;
+        float a[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) a[v] = 0.f;
+        if (in) *reinterpret_cast<V*>(a) = *reinterpret_cast<const V*>(Ai + c0);
+        const int64_t cl = in ? c0 : 0;
+        for (int k = b + wave; k < e; k += 4 * NW) {
+            int jc[4], ev[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = k + NW * u;
+                const int kc = kk < e ? kk : e - 1;
+                jc[u] = col[kc];
+                ev[u] = eid[kc];
+            }
+            float x[4][VEC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<V*>(x[u]) = *reinterpret_cast<const V*>(B + static_cast<int64_t>(jc[u]) * D + cl);
+            float d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float acc = 0.f;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc = fmaf(a[v], in ? x[u][v] : 0.f, acc);
+                d[u] = acc;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) d[u] += __shfl_xor(d[u], o, 64);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (k + NW * u < e) g[ev[u]] = d[u];
+            }
+        }
+        if (wave == 0 && gdiag) {
+            const float d0 = wave_sum_all(dot(i));
+            if (lane == 0) gdiag[i] = d0;
+        }
+        return;
+    }
     int k = b + wave;
     for (; k + NW < e; k += 2 * NW) {
         float d0 = dot(col[k]), d1 = dot(col[k + NW]);

@@ -111,19 +111,21 @@ __global__ void __launch_bounds__(64 * NW) gemm_tn_wg(const float* __restrict__ 
 // `N`, `ldc`: C is written with row stride ldc (>= N): the result may be a column block of a wider matrix (fc1.weight's halves)
 __global__ void __launch_bounds__(256) gemm_tn_reduce(const float* __restrict__ slab, int64_t mn, int ksplit, float* __restrict__ C,
                                                       const float* __restrict__ cpart = nullptr, int M = 0, float* __restrict__ colsum = nullptr,
-                                                      int N = 0, int64_t ldc = 0) {
+                                                      int N = 0, int64_t ldc = 0, const float* __restrict__ rowscale = nullptr,
+                                                      float scale = 1.f) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (i >= mn) {
         const int64_t c = i - mn;                       // trailing threads: the column sums of A, slices in the same fixed order
         if (colsum && c < M) {
             float acc = 0.f;
             for (int s = 0; s < ksplit; ++s) acc += cpart[static_cast<int64_t>(s) * M + c];
-            colsum[c] = acc;
+            colsum[c] = rowscale ? acc * (rowscale[c] * scale) : acc;
         }
         return;
     }
     float acc = 0.f;
     for (int s = 0; s < ksplit; ++s) acc += slab[static_cast<int64_t>(s) * mn + i];
+    if (rowscale) acc *= rowscale[i / N] * scale;        // mask-operand products: row m of C carries the factor left out of A
     if (ldc > 0 && ldc != N) C[(i / N) * ldc + (i % N)] = acc;
     else C[i] = acc;
 }
@@ -219,9 +221,13 @@ __global__ void __launch_bounds__(64) gemm_tn_tall_tile(const float* __restrict_
 // NW waves per workgroup, each with its own K-slice (ksplit = NW x gridDim.z slices in all): the NW partial tiles are summed
 // through LDS in a fixed tree before ONE slab per workgroup is written, so the slab reduction that follows reads 1 / NW of the
 // bytes (K = 100 000, M = N = 256: 128 slices -> 32 slabs of 256 KB; the reduction launch drops from 32 us to the launch floor).
-template <int NW>
+// MASK: A is a 0 / 1 matrix given as bits (Abits [K, M/32], bit m of row k) times a per-row factor dz[k]: the scorer's
+// dv = diag(dz) mask diag(w2 / (1 - p)).  The mask is ONE exact bf16 piece and dz moves to the B side (b <- dz[k] * b before the split), so
+// a product is 3 MFMAs instead of 6 and the A stream is 1/32 of the bytes; the column factor w2 / (1 - p) is applied by gemm_tn_reduce.
+template <int NW, bool MASK = false>
 __global__ void __launch_bounds__(64 * NW) gemm_tn_tall_bf16x6(const float* __restrict__ A, const float* __restrict__ B, int64_t K, int M, int N,
-                                                              int ksplit, float* __restrict__ slab, float* __restrict__ cpart) {
+                                                              int ksplit, float* __restrict__ slab, float* __restrict__ cpart,
+                                                              const uint32_t* __restrict__ Abits = nullptr, const float* __restrict__ dz = nullptr) {
     extern __shared__ float red_lds[];       // NW > 1: [NW / 2][8 tiles x 16 registers][64 lanes] partial tiles + [NW / 2][4][64] column sums
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, l31 = lane & 31;
     const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 64, s = blockIdx.z * NW + wave;
@@ -240,31 +246,77 @@ __global__ void __launch_bounds__(64 * NW) gemm_tn_tall_bf16x6(const float* __re
     const float2 z2 = make_float2(0.f, 0.f);
     const bool want_cs = cpart != nullptr && blockIdx.y == 0;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
-    struct Raw { float4 a[8]; float2 b[8]; };
+    struct Raw { float4 a[8]; float2 b[8]; uint32_t aw[8]; float dzr[8]; int64_t k; };      // (a | aw, dzr: the unused ones are never live)
+    const int wsel = ia >> 5, wsh = ia & 31;
     auto load = [&](int64_t k, Raw& r) {
+        r.k = k;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int64_t kk = k + 8 * g + j;
             const bool in = kk < k1;
-            r.a[j] = (aok && in) ? *reinterpret_cast<const float4*>(A + kk * M + ia) : z4;
-            r.b[j] = (bok && in) ? *reinterpret_cast<const float2*>(B + kk * N + jb) : z2;
+            if constexpr (MASK) {
+                // UNCONDITIONAL loads of a clamped row, raw values only: a load under `in ? .. : 0` with arithmetic on its result
+                // compiles to a branch with a vmcnt(0) wait inside -- eight serialised round trips per step (measured: 2.1 x slower).
+                // Rows past the slice are neutralised in mma() through dz = 0.
+                const int64_t kc = in ? kk : k1 - 1;
+                r.aw[j] = Abits[kc * (M >> 5) + wsel];
+                r.dzr[j] = dz[kc];
+                r.b[j] = *reinterpret_cast<const float2*>(B + kc * N + jb);      // (N % 64 == 0: sgs_gemm_tn_mask_supported)
+            } else {
+                r.a[j] = (aok && in) ? *reinterpret_cast<const float4*>(A + kk * M + ia) : z4;
+                r.b[j] = (bok && in) ? *reinterpret_cast<const float2*>(B + kk * N + jb) : z2;
+            }
         }
     };
-    auto mma = [&](const Raw& r) {
+    auto mma = [&](const Raw& r_) {
+        Raw r = r_;
+        if constexpr (MASK) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                r.aw[j] >>= wsh;                                    // bits of columns ia .. ia + 3 in the low nibble
+                if (r.k + 8 * g + j >= k1) r.dzr[j] = 0.f;
+            }
+        }
         if (want_cs) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { cs[0] += r.a[j].x; cs[1] += r.a[j].y; cs[2] += r.a[j].z; cs[3] += r.a[j].w; }
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (MASK) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) cs[t] += (r.aw[j] >> t) & 1u ? r.dzr[j] : 0.f;
+                } else {
+                    cs[0] += r.a[j].x; cs[1] += r.a[j].y; cs[2] += r.a[j].z; cs[3] += r.a[j].w;
+                }
+            }
         }
         u32x4 Bp[2][3];
 #pragma unroll
         for (int w = 0; w < 2; ++w)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const float e0 = w == 0 ? r.b[2 * m].x : r.b[2 * m].y, e1 = w == 0 ? r.b[2 * m + 1].x : r.b[2 * m + 1].y;
+                float e0 = w == 0 ? r.b[2 * m].x : r.b[2 * m].y, e1 = w == 0 ? r.b[2 * m + 1].x : r.b[2 * m + 1].y;
+                if constexpr (MASK) { e0 *= r.dzr[2 * m]; e1 *= r.dzr[2 * m + 1]; }
                 uint32_t p1, p2, p3;
                 split3(e0, e1, p1, p2, p3);
                 Bp[w][0][m] = p1; Bp[w][1][m] = p2; Bp[w][2][m] = p3;
             }
+        if constexpr (MASK) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                u32x4 A1;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    A1[m] = ((r.aw[2 * m] >> t) & 1u ? 0x3F80u : 0u) | ((r.aw[2 * m + 1] >> t) & 1u ? 0x3F800000u : 0u);
+                const bf16x8 a1 = __builtin_bit_cast(bf16x8, A1);
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const bf16x8 b1 = __builtin_bit_cast(bf16x8, Bp[w][0]), b2 = __builtin_bit_cast(bf16x8, Bp[w][1]), b3 = __builtin_bit_cast(bf16x8, Bp[w][2]);
+                    acc[t][w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t][w], 0, 0, 0);     // smallest terms first
+                    acc[t][w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t][w], 0, 0, 0);
+                    acc[t][w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t][w], 0, 0, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             u32x4 Ap[3];
@@ -380,7 +432,8 @@ size_t sgs_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N) {
 }
 
 static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, float* colsum_A, void* ws,
-                        size_t ws_bytes, hipStream_t stream, int64_t ldc = 0);
+                        size_t ws_bytes, hipStream_t stream, int64_t ldc = 0, const uint32_t* Abits = nullptr, const float* dz = nullptr,
+                        const float* rowscale = nullptr, float scale = 1.f);
 // tall-K shapes: 1 = bf16x6 kernel (default; measured 147 vs 175 us incl. the 34 us slab reduction at K = 100 000, M = N = 256: the
 // operand splits, 264 vector instructions per 48 MFMAs, are at the budget the matrix pipe leaves), 0 = fp32-MFMA kernel
 static int g_tall_bf16x6 = 1;
@@ -407,11 +460,29 @@ int sgs_gemm_tn_ld(const float* A, const float* B, int64_t K, int64_t M, int64_t
     return gemm_tn_impl(A, B, K, M, N, C, colsum_A, ws, ws_bytes, static_cast<hipStream_t>(stream_), ldc);
 }
 
+/* C[M, N] (row stride ldc) = (diag(dz) mask diag(rowscale * scale))^T B with the mask given as bits [K, M/32] (bit m of row k): the weight
+ * gradient d W1a = dv^T feat of the scorer with dv in its mask form (sgs_edge_score_bwd_core_bits); colsum_A (optional) = the column sums of
+ * that dv = d b1.  Served by the tall-K bf16 kernel only: sgs_gemm_tn_mask_supported. */
+int sgs_gemm_tn_mask_supported(int64_t K, int64_t M, int64_t N) {
+    if (!use_tall(K, M, N) || M % 128 != 0 || N % 64 != 0) return 0;      // whole 128 x 64 wave tiles: the operands are read unconditionally
+    const int ks = pick_ksplit_tall(K, M, N);
+    return (ks >= 4 && ks % 4 == 0) ? 1 : 0;
+}
+
+int sgs_gemm_tn_mask(const uint32_t* Abits, const float* dz, const float* rowscale, float scale, const float* B, int64_t K, int64_t M, int64_t N,
+                     float* C, int64_t ldc, float* colsum_A, void* ws, size_t ws_bytes, sgs_stream_t stream_) {
+    SGS_REQUIRE(ldc >= N, SGS_EINVAL, "sgs_gemm_tn_mask: ldc < N");
+    SGS_REQUIRE(Abits && dz && rowscale, SGS_EINVAL, "sgs_gemm_tn_mask: null pointer");
+    SGS_REQUIRE(sgs_gemm_tn_mask_supported(K, M, N), SGS_EINVAL, "sgs_gemm_tn_mask: shape not served (check sgs_gemm_tn_mask_supported)");
+    return gemm_tn_impl(nullptr, B, K, M, N, C, colsum_A, ws, ws_bytes, static_cast<hipStream_t>(stream_), ldc, Abits, dz, rowscale, scale);
+}
+
 static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, float* colsum_A, void* ws,
-                        size_t ws_bytes, hipStream_t stream, int64_t ldc) {
+                        size_t ws_bytes, hipStream_t stream, int64_t ldc, const uint32_t* Abits, const float* dz, const float* rowscale,
+                        float scale) {
     SGS_REQUIRE(K >= 0 && M >= 0 && N >= 0 && M < (1 << 30) && N < (1 << 30), SGS_EINVAL, "sgs_gemm_tn: bad sizes");
     if (M == 0 || N == 0) return SGS_OK;
-    SGS_REQUIRE(C && (K == 0 || (A && B)), SGS_EINVAL, "sgs_gemm_tn: null pointer");
+    SGS_REQUIRE(C && (K == 0 || ((A || Abits) && B)), SGS_EINVAL, "sgs_gemm_tn: null pointer");
     SGS_REQUIRE(ws && ws_bytes >= sgs_gemm_tn_workspace_bytes(K, M, N), SGS_EWORKSPACE, "sgs_gemm_tn: workspace too small");
     const int ks = pick_ksplit(K, M, N);
     Carver cv(ws);
@@ -420,6 +491,24 @@ static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, in
     const bool strided = ldc > 0 && ldc != N;                  // the tile kernels write dense [M, N]: a strided C goes through the reduce
     float* dst = (ks == 1 && !strided) ? C : slab;
     int n_slabs = ks;                                          // slabs the reduction launch sums (= K-slices unless waves share a workgroup)
+    if (Abits) {
+        constexpr int NW = 4;
+        constexpr size_t lds = (NW / 2) * (128 * 64 + 4 * 64) * sizeof(float);
+        static bool raised_m = false;
+        if (!raised_m) {
+            SGS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_tall_bf16x6<NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds)));
+            raised_m = true;
+        }
+        n_slabs = ks / NW;
+        hipLaunchKernelGGL((gemm_tn_tall_bf16x6<NW, true>), dim3(cdiv(M, 128), cdiv(N, 64), n_slabs), dim3(64 * NW), lds, stream, A, B, K,
+                           static_cast<int>(M), static_cast<int>(N), ks, slab, colsum_A ? cpart : static_cast<float*>(nullptr), Abits, dz);
+        hipLaunchKernelGGL(gemm_tn_reduce, dim3(cdiv(M * N + (colsum_A ? M : 0), 256)), dim3(256), 0, stream, slab, M * N, n_slabs, C,
+                           static_cast<const float*>(colsum_A ? cpart : nullptr), static_cast<int>(M), colsum_A, static_cast<int>(N),
+                           ldc > 0 ? ldc : N, rowscale, scale);
+        SGS_LAUNCH_OK();
+        return SGS_OK;
+    }
     if (use_tall(K, M, N) && g_tall_bf16x6 && ks >= 4 && ks % 4 == 0) {
         constexpr int NW = 4;
         constexpr size_t lds = (NW / 2) * (128 * 64 + 4 * 64) * sizeof(float);

@@ -4,6 +4,7 @@ and autograd bookkeeping only; every numeric step of the hot path runs in libsgs
 Nothing here computes on the CPU: a non-HIP tensor raises."""
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -565,6 +566,9 @@ def _endpoint_reduce(M_out, M_in, T, graph: Graph, s_out, s_in, H):
     return out
 
 
+_mask_backward = True        # False: the dense fp32 dv path at every size (tests compare the two)
+
+
 class _EdgeScore(torch.autograd.Function):
     """K1b with the node-level half of fc1 inside: U = codes W1b^T (library GEMM) in forward; in backward d codes gets dU W1b on
     top of the direct term, and BOTH halves of d fc1.weight [H, 2H] are written in place by the two weight-gradient GEMMs
@@ -616,6 +620,9 @@ class _EdgeScore(torch.autograd.Function):
             eid, graph, n = None, get_graph(edge_index, N), E
             gp_act = gp.contiguous()
         f32 = dict(dtype=torch.float32, device=dev)
+        if (_mask_backward and n >= 65536 and N <= 65536 and L.sgs_edge_score_bwd_bits_supported(H) and L.sgs_gemm_tn_mask_supported(n, H, H)
+                and ctx.needs_input_grad[0]):
+            return _EdgeScore._backward_mask(ctx, L, codes, U, W1, b1, w2, b2, edge_index, eid, graph, n, gp_act)
         dv, feat = torch.empty(n, H, **f32), torch.empty(n, H, **f32)
         tile = L.sgs_edge_score_bwd_tile()
         hdz = torch.empty((n + tile - 1) // tile, H, **f32)          # per-tile column sums of dz * hidden (rows sum to d w2)
@@ -666,6 +673,51 @@ class _EdgeScore(torch.autograd.Function):
         _lib.check(L.sgs_gemm_tn_ld(_ptr(dU), _ptr(codes), N, H, H, dW1.data_ptr() + 4 * H, 2 * H, None, wsb.data_ptr(), wsb.numel(), _stream()),
                    "sgs_gemm_tn_ld")
         return dcodes, dW1, db1, dw2, db2, None, None, None, None, None, None, None
+
+
+def _edge_score_backward_mask(ctx, L, codes, U, W1, b1, w2, b2, edge_index, eid, graph, n, gp_act):
+    """The backward at production size in its MASK form (include/sgs_hip.h, sgs_edge_score_bwd_core_bits): dv = dz x [hidden > 0] x w2 / (1 - p)
+    never exists as an fp32 [n, H] matrix -- the core writes one bit per entry and the three consumers rebuild what they need, the two
+    contractions with a 0 / 1 operand at half the MFMA work."""
+    N, H = codes.shape
+    E = edge_index.shape[1]
+    dev = codes.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    p = ctx.p
+    bits = torch.empty(n, H // 32, dtype=torch.int32, device=dev)
+    feat = torch.empty(n, H, **f32)
+    tile = L.sgs_edge_score_bwd_tile()
+    hdz = torch.empty((n + tile - 1) // tile, H, **f32)
+    dz = torch.empty(n, **f32)
+    ws = workspace(L.sgs_edge_score_workspace_bytes(N, H, 0), dev)
+    _lib.check(L.sgs_edge_score_bwd_core_bits(_ptr(codes), _ptr(U), N, H, _ptr(edge_index), E, ctx.offset, _ptr(eid), n, _ptr(gp_act), _ptr(W1),
+                                              _ptr(b1), _ptr(w2), _ptr(b2), p, ctx.seed, ctx.site, _ptr(bits), _ptr(hdz), _ptr(dz), _ptr(feat),
+                                              ws.data_ptr(), ws.numel(), _stream()), "sgs_edge_score_bwd_core_bits")
+    dfeat = torch.empty(n, H, **f32)
+    wsd = workspace(L.sgs_edge_score_workspace_bytes(0, H, 0), dev)
+    _lib.check(L.sgs_edge_score_bwd_dfeat_bits(_ptr(bits), _ptr(dz), n, H, _ptr(W1), _ptr(w2), p, _ptr(dfeat), wsd.data_ptr(), wsd.numel(),
+                                               _stream()), "sgs_edge_score_bwd_dfeat_bits")
+    dW1 = torch.empty_like(W1)
+    db1 = torch.empty(H, **f32)
+    scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))        # as the kernels form it: 1.0f / (1.0f - p)
+    wsg = workspace(L.sgs_gemm_tn_workspace_bytes(n, H, H), dev)
+    _lib.check(L.sgs_gemm_tn_mask(_ptr(bits), _ptr(dz), _ptr(w2), scale, _ptr(feat), n, H, H, _ptr(dW1), 2 * H, _ptr(db1), wsg.data_ptr(),
+                                  wsg.numel(), _stream()), "sgs_gemm_tn_mask")
+    dw2 = _colsum(hdz)
+    db2 = _colsum(dz.view(n, 1)).reshape(1)
+    dcodes = torch.empty(N, H, **f32)
+    dU = torch.empty(N, H, **f32)
+    _lib.check(L.sgs_endpoint_reduce_pair_bits(_ptr(dfeat), _ptr(bits), _ptr(dz), _ptr(w2), p, _ptr(codes), N, H, graph.n_edges, _ptr(graph.in_ptr),
+                                               _ptr(graph.in_src), _ptr(graph.in_eid), _ptr(graph.out_ptr), _ptr(graph.out_dst),
+                                               _ptr(graph.out_eid), _ptr(dcodes), _ptr(dU), _stream()), "sgs_endpoint_reduce_pair_bits")
+    dcodes.addmm_(dU, W1[:, H:])
+    wsb = workspace(L.sgs_gemm_tn_workspace_bytes(N, H, H), dev)
+    _lib.check(L.sgs_gemm_tn_ld(_ptr(dU), _ptr(codes), N, H, H, dW1.data_ptr() + 4 * H, 2 * H, None, wsb.data_ptr(), wsb.numel(), _stream()),
+               "sgs_gemm_tn_ld")
+    return dcodes, dW1, db1, dw2, db2, None, None, None, None, None, None, None
+
+
+_EdgeScore._backward_mask = staticmethod(_edge_score_backward_mask)
 
 
 def edge_score(codes, fc1_w, fc1_b, fc2_w, fc2_b, edge_index, active=None, p=0.0, seed=0, site=0, edge_id_offset=0, pairs="cached"):

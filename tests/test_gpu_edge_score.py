@@ -122,6 +122,34 @@ def test_production_size_forward_and_active_backward_vs_fp64_oracle(ops, p):
             assert _rel(a.grad, b.grad) < 2e-5, (name, _rel(a.grad, b.grad))
 
 
+@pytest.mark.parametrize("H,p", [(256, 0.3), (128, 0.0), (256, 0.0)])
+def test_mask_backward_equals_dense_backward(ops, H, p):
+    """The mask form of the backward (one bit per entry of dv; 0 / 1 operands in the two contractions, 3 bf16 products instead of 6)
+    against the dense fp32-dv path on the same inputs: the same five gradients to fp32 rounding (they differ only in where the row and
+    column factors dz, w2 / (1 - p) are multiplied in)."""
+    N, E, q = 777, 140_000, 66_000
+    codes, ei, W1, b1, W2, b2, g = _case(N, H, E, 99)
+    eid = torch.sort(torch.randperm(E, generator=g)[:q]).values
+    gp = torch.zeros(E)
+    gp[eid] = torch.randn(q, generator=g)
+    sub = ei[:, eid]
+    grads = {}
+    for mask in (True, False):
+        ops._mask_backward = mask
+        try:
+            dl = [t.clone().to(DEV).requires_grad_(True) for t in (codes, W1, b1, W2, b2)]
+            act = ops.ActiveSet()
+            pd = ops.edge_score(dl[0], dl[1], dl[2], dl[3], dl[4], ei.to(DEV), active=act, p=p, seed=5, site=2)
+            act.set(eid.to(DEV), ops.Graph(sub.to(DEV), N))
+            pd.backward(gp.to(DEV))
+            grads[mask] = [t.grad.detach().cpu() for t in dl]
+        finally:
+            ops._mask_backward = True
+    for name, a, b in zip(["dcodes", "dW1", "db1", "dW2", "db2"], grads[True], grads[False]):
+        assert bool(torch.isfinite(a).all()), name
+        assert _rel(a, b) < 3e-6, (name, _rel(a, b))
+
+
 @pytest.mark.parametrize("H,p", [(256, 0.3), (128, 0.0)])
 def test_paired_forward_equals_plain_forward_bitwise(ops, H, p):
     """sgs_edge_score_fwd_paired (only the canonical edge of every (s -> d), (d -> s) pair runs the H x H contraction; both scores
