@@ -379,10 +379,11 @@ int sgs_endpoint_reduce_pair_bits(const float* dfeat, const uint32_t* dvbits, co
                                   const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid, float* out_codes, float* out_U,
                                   sgs_stream_t stream);
 /* C[M, N] (row stride ldc) = (diag(dz) mask diag(rowscale * scale))^T B, mask bits [K, M/32]; colsum_A (optional, [M]) = that matrix's column
- * sums.  Tall-K shapes only (sgs_gemm_tn_mask_supported); ws: sgs_gemm_tn_workspace_bytes(K, M, N). */
+ * sums; dz_sum (optional, [1]) = sum_k dz[k] (d fc2.bias rides along).  Tall-K shapes only (sgs_gemm_tn_mask_supported);
+ * ws: sgs_gemm_tn_workspace_bytes(K, M, N). */
 int sgs_gemm_tn_mask_supported(int64_t K, int64_t M, int64_t N);
 int sgs_gemm_tn_mask(const uint32_t* Abits, const float* dz, const float* rowscale, float scale, const float* B, int64_t K, int64_t M, int64_t N,
-                     float* C, int64_t ldc, float* colsum_A, void* ws, size_t ws_bytes, sgs_stream_t stream);
+                     float* C, int64_t ldc, float* colsum_A, float* dz_sum, void* ws, size_t ws_bytes, sgs_stream_t stream);
 
 int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, int64_t N, int64_t H, int64_t nnz,
                         const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid, const int32_t* out_ptr,

@@ -112,10 +112,16 @@ __global__ void __launch_bounds__(64 * NW) gemm_tn_wg(const float* __restrict__ 
 __global__ void __launch_bounds__(256) gemm_tn_reduce(const float* __restrict__ slab, int64_t mn, int ksplit, float* __restrict__ C,
                                                       const float* __restrict__ cpart = nullptr, int M = 0, float* __restrict__ colsum = nullptr,
                                                       int N = 0, int64_t ldc = 0, const float* __restrict__ rowscale = nullptr,
-                                                      float scale = 1.f) {
+                                                      float scale = 1.f, const float* __restrict__ dzpart = nullptr, int nz = 0,
+                                                      float* __restrict__ dzsum = nullptr) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (i >= mn) {
         const int64_t c = i - mn;                       // trailing threads: the column sums of A, slices in the same fixed order
+        if (dzsum && c == M) {                          // one more: the sum of the mask operand's row factors (d fc2.bias), slice by slice
+            float acc = 0.f;
+            for (int z = 0; z < nz; ++z) acc += dzpart[z];
+            dzsum[0] = acc;
+        }
         if (colsum && c < M) {
             float acc = 0.f;
             for (int s = 0; s < ksplit; ++s) acc += cpart[static_cast<int64_t>(s) * M + c];
@@ -227,9 +233,11 @@ __global__ void __launch_bounds__(64) gemm_tn_tall_tile(const float* __restrict_
 template <int NW, bool MASK = false>
 __global__ void __launch_bounds__(64 * NW) gemm_tn_tall_bf16x6(const float* __restrict__ A, const float* __restrict__ B, int64_t K, int M, int N,
                                                               int ksplit, float* __restrict__ slab, float* __restrict__ cpart,
-                                                              const uint32_t* __restrict__ Abits = nullptr, const float* __restrict__ dz = nullptr) {
+                                                              const uint32_t* __restrict__ Abits = nullptr, const float* __restrict__ dz = nullptr,
+                                                              float* __restrict__ dzpart = nullptr) {
     extern __shared__ float red_lds[];       // NW > 1: [NW / 2][8 tiles x 16 registers][64 lanes] partial tiles + [NW / 2][4][64] column sums
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, l31 = lane & 31;
+    const int lane = threadIdx.x & 63, g = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform, and the compiler should know: slice bounds in SGPRs
     const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 64, s = blockIdx.z * NW + wave;
     const int ia = m0 + 4 * l31, jb = n0 + 2 * l31;
     const bool aok = ia < M, bok = jb < N;
@@ -246,35 +254,67 @@ __global__ void __launch_bounds__(64 * NW) gemm_tn_tall_bf16x6(const float* __re
     const float2 z2 = make_float2(0.f, 0.f);
     const bool want_cs = cpart != nullptr && blockIdx.y == 0;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool want_dz = MASK && dzpart != nullptr && blockIdx.x == 0 && blockIdx.y == 0;      // the slice's sum of dz (d fc2.bias) on the way
+    float dzs = 0.f;
     struct Raw { float4 a[8]; float2 b[8]; uint32_t aw[8]; float dzr[8]; int64_t k; };      // (a | aw, dzr: the unused ones are never live)
     const int wsel = ia >> 5, wsh = ia & 31;
+    // MASK: per-lane bases of the slice, so that a step's 24 loads are base + (row-in-slice) * stride in 32-bit arithmetic (64-bit index
+    // math per load made this loop VALU-bound: ~620 vector instructions per 24 MFMAs, measured 92 us; the matrix work is 16 us)
+    const int wpr = M >> 5;                                                 // mask words per row
+    const int lim = static_cast<int>(k1 - k0);                              // rows in this slice (<= 0: an empty trailing slice)
+    const uint32_t* Ab = MASK ? Abits + k0 * wpr + wsel : nullptr;
+    const float* Db = MASK ? dz + k0 : nullptr;
+    const float* Bb = B + k0 * N + jb;
     auto load = [&](int64_t k, Raw& r) {
         r.k = k;
+        if constexpr (MASK) {
+            // UNCONDITIONAL loads, raw values only (a load under `in ? .. : 0` with arithmetic on its result compiles to a branch with a
+            // vmcnt(0) wait inside: eight serialised round trips per step, 2.1 x slower).  Whole steps (all but a slice's last) need no
+            // clamping at all; rows past the slice read its last row and are neutralised in mma() through dz = 0.
+            const int rel = static_cast<int>(k - k0) + 8 * g;
+            if (k + 16 <= k1) {                                             // (wave-uniform)
+                const uint32_t* a = Ab + rel * wpr;
+                const float* d = Db + rel;
+                const float* b = Bb + static_cast<int64_t>(rel) * N;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    r.aw[j] = a[j * wpr];
+                    r.dzr[j] = d[j];
+                    r.b[j] = *reinterpret_cast<const float2*>(b + j * N);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int rc = min(rel + j, lim - 1);
+                    r.aw[j] = Ab[rc * wpr];
+                    r.dzr[j] = Db[rc];
+                    r.b[j] = *reinterpret_cast<const float2*>(Bb + static_cast<int64_t>(rc) * N);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int64_t kk = k + 8 * g + j;
             const bool in = kk < k1;
-            if constexpr (MASK) {
-                // UNCONDITIONAL loads of a clamped row, raw values only: a load under `in ? .. : 0` with arithmetic on its result
-                // compiles to a branch with a vmcnt(0) wait inside -- eight serialised round trips per step (measured: 2.1 x slower).
-                // Rows past the slice are neutralised in mma() through dz = 0.
-                const int64_t kc = in ? kk : k1 - 1;
-                r.aw[j] = Abits[kc * (M >> 5) + wsel];
-                r.dzr[j] = dz[kc];
-                r.b[j] = *reinterpret_cast<const float2*>(B + kc * N + jb);      // (N % 64 == 0: sgs_gemm_tn_mask_supported)
-            } else {
-                r.a[j] = (aok && in) ? *reinterpret_cast<const float4*>(A + kk * M + ia) : z4;
-                r.b[j] = (bok && in) ? *reinterpret_cast<const float2*>(B + kk * N + jb) : z2;
-            }
+            r.a[j] = (aok && in) ? *reinterpret_cast<const float4*>(A + kk * M + ia) : z4;
+            r.b[j] = (bok && in) ? *reinterpret_cast<const float2*>(B + kk * N + jb) : z2;
         }
     };
     auto mma = [&](const Raw& r_) {
         Raw r = r_;
         if constexpr (MASK) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                r.aw[j] >>= wsh;                                    // bits of columns ia .. ia + 3 in the low nibble
-                if (r.k + 8 * g + j >= k1) r.dzr[j] = 0.f;
+            for (int j = 0; j < 8; ++j) r.aw[j] >>= wsh;            // bits of columns ia .. ia + 3 in the low nibble
+            if (r.k + 16 > k1) {                                    // (wave-uniform) the slice's last step: rows past it count for nothing
+                const int rel = static_cast<int>(r.k - k0) + 8 * g;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (rel + j >= lim) r.dzr[j] = 0.f;
+            }
+            if (want_dz) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dzs += r.dzr[j];
             }
         }
         if (want_cs) {
@@ -305,7 +345,7 @@ __global__ void __launch_bounds__(64 * NW) gemm_tn_tall_bf16x6(const float* __re
                 u32x4 A1;
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
-                    A1[m] = ((r.aw[2 * m] >> t) & 1u ? 0x3F80u : 0u) | ((r.aw[2 * m + 1] >> t) & 1u ? 0x3F800000u : 0u);
+                    A1[m] = ((r.aw[2 * m] >> t) & 1u) * 0x3F80u + ((r.aw[2 * m + 1] >> t) & 1u) * 0x3F800000u;      // bf16 1.0 / 0.0 pairs
                 const bf16x8 a1 = __builtin_bit_cast(bf16x8, A1);
 #pragma unroll
                 for (int w = 0; w < 2; ++w) {
@@ -343,17 +383,39 @@ __global__ void __launch_bounds__(64 * NW) gemm_tn_tall_bf16x6(const float* __re
         }
     };
     Raw r0, r1;
-    load(k0, r0);
+    if (!MASK || lim > 0) load(k0, r0);
+    if constexpr (MASK) {
+        if (lim > 0) {
+        // a stage is 32 registers here (against 48), so THREE are kept: two steps of loads in flight behind the one being multiplied --
+        // with one wave per SIMD the loop runs at the memory latency per step, and the second stage in flight halves it (measured)
+        Raw r2;
+        load(k0 + 16, r1);
 #pragma unroll 1
-    for (int64_t k = k0; k < k1; k += 32) {
-        load(k + 16, r1);                                   // rows past k1 load zeros
-        mma(r0);
-        load(k + 32, r0);
-        mma(r1);
+        for (int64_t k = k0; k < k1; k += 48) {
+            load(k + 32, r2);                               // rows past k1: a clamped row with dz = 0
+            mma(r0);
+            load(k + 48, r0);
+            mma(r1);
+            load(k + 64, r1);
+            mma(r2);
+        }
+        }
+    } else {
+#pragma unroll 1
+        for (int64_t k = k0; k < k1; k += 32) {
+            load(k + 16, r1);                                   // rows past k1 load zeros
+            mma(r0);
+            load(k + 32, r0);
+            mma(r1);
+        }
     }
     if (want_cs) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) cs[t] += __shfl_xor(cs[t], 32, 64);          // the two 8-row groups of every step
+    }
+    if (want_dz) {
+        dzs += __shfl_xor(dzs, 32, 64);
+        if (lane == 0) dzpart[s] = dzs;                                          // one entry per K-slice; gemm_tn_reduce adds them in order
     }
     if (NW > 1) {
         // fixed tree over the workgroup's waves: upper half stores, lower half adds, halve, repeat (lane-major: conflict-free)
@@ -433,7 +495,7 @@ size_t sgs_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N) {
 
 static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, float* colsum_A, void* ws,
                         size_t ws_bytes, hipStream_t stream, int64_t ldc = 0, const uint32_t* Abits = nullptr, const float* dz = nullptr,
-                        const float* rowscale = nullptr, float scale = 1.f);
+                        const float* rowscale = nullptr, float scale = 1.f, float* dz_sum = nullptr);
 // tall-K shapes: 1 = bf16x6 kernel (default; measured 147 vs 175 us incl. the 34 us slab reduction at K = 100 000, M = N = 256: the
 // operand splits, 264 vector instructions per 48 MFMAs, are at the budget the matrix pipe leaves), 0 = fp32-MFMA kernel
 static int g_tall_bf16x6 = 1;
@@ -470,16 +532,16 @@ int sgs_gemm_tn_mask_supported(int64_t K, int64_t M, int64_t N) {
 }
 
 int sgs_gemm_tn_mask(const uint32_t* Abits, const float* dz, const float* rowscale, float scale, const float* B, int64_t K, int64_t M, int64_t N,
-                     float* C, int64_t ldc, float* colsum_A, void* ws, size_t ws_bytes, sgs_stream_t stream_) {
+                     float* C, int64_t ldc, float* colsum_A, float* dz_sum, void* ws, size_t ws_bytes, sgs_stream_t stream_) {
     SGS_REQUIRE(ldc >= N, SGS_EINVAL, "sgs_gemm_tn_mask: ldc < N");
     SGS_REQUIRE(Abits && dz && rowscale, SGS_EINVAL, "sgs_gemm_tn_mask: null pointer");
     SGS_REQUIRE(sgs_gemm_tn_mask_supported(K, M, N), SGS_EINVAL, "sgs_gemm_tn_mask: shape not served (check sgs_gemm_tn_mask_supported)");
-    return gemm_tn_impl(nullptr, B, K, M, N, C, colsum_A, ws, ws_bytes, static_cast<hipStream_t>(stream_), ldc, Abits, dz, rowscale, scale);
+    return gemm_tn_impl(nullptr, B, K, M, N, C, colsum_A, ws, ws_bytes, static_cast<hipStream_t>(stream_), ldc, Abits, dz, rowscale, scale, dz_sum);
 }
 
 static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, float* colsum_A, void* ws,
                         size_t ws_bytes, hipStream_t stream, int64_t ldc, const uint32_t* Abits, const float* dz, const float* rowscale,
-                        float scale) {
+                        float scale, float* dz_sum) {
     SGS_REQUIRE(K >= 0 && M >= 0 && N >= 0 && M < (1 << 30) && N < (1 << 30), SGS_EINVAL, "sgs_gemm_tn: bad sizes");
     if (M == 0 || N == 0) return SGS_OK;
     SGS_REQUIRE(C && (K == 0 || ((A || Abits) && B)), SGS_EINVAL, "sgs_gemm_tn: null pointer");
@@ -501,11 +563,14 @@ static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, in
             raised_m = true;
         }
         n_slabs = ks / NW;
+        // cpart holds ks * M floats and the NW-wave workgroups fill n_slabs * M of them: the K-slices' dz sums go behind those
+        float* dzpart = dz_sum ? cpart + static_cast<size_t>(n_slabs) * M : nullptr;
         hipLaunchKernelGGL((gemm_tn_tall_bf16x6<NW, true>), dim3(cdiv(M, 128), cdiv(N, 64), n_slabs), dim3(64 * NW), lds, stream, A, B, K,
-                           static_cast<int>(M), static_cast<int>(N), ks, slab, colsum_A ? cpart : static_cast<float*>(nullptr), Abits, dz);
-        hipLaunchKernelGGL(gemm_tn_reduce, dim3(cdiv(M * N + (colsum_A ? M : 0), 256)), dim3(256), 0, stream, slab, M * N, n_slabs, C,
+                           static_cast<int>(M), static_cast<int>(N), ks, slab, (colsum_A || dz_sum) ? cpart : static_cast<float*>(nullptr), Abits, dz,
+                           dzpart);
+        hipLaunchKernelGGL(gemm_tn_reduce, dim3(cdiv(M * N + M + 1, 256)), dim3(256), 0, stream, slab, M * N, n_slabs, C,
                            static_cast<const float*>(colsum_A ? cpart : nullptr), static_cast<int>(M), colsum_A, static_cast<int>(N),
-                           ldc > 0 ? ldc : N, rowscale, scale);
+                           ldc > 0 ? ldc : N, rowscale, scale, static_cast<const float*>(dzpart), ks, dz_sum);
         SGS_LAUNCH_OK();
         return SGS_OK;
     }

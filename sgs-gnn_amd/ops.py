@@ -701,10 +701,10 @@ def _edge_score_backward_mask(ctx, L, codes, U, W1, b1, w2, b2, edge_index, eid,
     db1 = torch.empty(H, **f32)
     scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))        # as the kernels form it: 1.0f / (1.0f - p)
     wsg = workspace(L.sgs_gemm_tn_workspace_bytes(n, H, H), dev)
-    _lib.check(L.sgs_gemm_tn_mask(_ptr(bits), _ptr(dz), _ptr(w2), scale, _ptr(feat), n, H, H, _ptr(dW1), 2 * H, _ptr(db1), wsg.data_ptr(),
+    db2 = torch.empty(1, **f32)
+    _lib.check(L.sgs_gemm_tn_mask(_ptr(bits), _ptr(dz), _ptr(w2), scale, _ptr(feat), n, H, H, _ptr(dW1), 2 * H, _ptr(db1), _ptr(db2), wsg.data_ptr(),
                                   wsg.numel(), _stream()), "sgs_gemm_tn_mask")
     dw2 = _colsum(hdz)
-    db2 = _colsum(dz.view(n, 1)).reshape(1)
     dcodes = torch.empty(N, H, **f32)
     dU = torch.empty(N, H, **f32)
     _lib.check(L.sgs_endpoint_reduce_pair_bits(_ptr(dfeat), _ptr(bits), _ptr(dz), _ptr(w2), p, _ptr(codes), N, H, graph.n_edges, _ptr(graph.in_ptr),
