@@ -743,22 +743,6 @@ __global__ void __launch_bounds__(kT) pack_w1a_bf16x3(const float* __restrict__ 
 // sign of the node-level term U[s] - U[d] and in their dropout rows.  So only the canonical edge of every mated pair (and every
 // unmated edge) runs the main loop -- about half of the candidate edges -- and the epilogue finishes BOTH scores from the one
 // set of accumulators: the same p as MODE 0, bit for bit, at ~0.6 x the time.
-// Sum over each 32-lane half of the wave on the DPP path (no LDS traffic): four in-row steps (quad_perm xor 1, xor 2, row_half_mirror,
-// row_mirror) leave every lane with its 16-lane row sum, row_bcast15 into rows 1 and 3 adds the row before.  Lanes 16..31 / 48..63 hold
-// the result.  (As __shfl_xor steps the compiler emitted 649 ds_bpermute_b32 with a wait each in the backward core: a third of a tile's time.)
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ float dpp_get(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
-}
-__device__ __forceinline__ float half_wave_sum_hi(float v) {
-    v += dpp_get<0xB1>(v);            // quad_perm [1,0,3,2]
-    v += dpp_get<0x4E>(v);            // quad_perm [2,3,0,1]
-    v += dpp_get<0x141>(v);           // row_half_mirror
-    v += dpp_get<0x140>(v);           // row_mirror
-    v += dpp_get<0x142, 0xA>(v);      // row_bcast15 -> rows 1 and 3 (rows 0 and 2 add 0)
-    return v;
-}
-
 template <int NT, int NW, int MODE = 0>
 __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(ScoreArgs a, const uint4* __restrict__ Wp16) {
     constexpr bool BWD = MODE == 1, GEMMB = MODE == 4, GEMM = MODE == 2 || MODE == 4, PAIR = MODE == 3;
@@ -1035,7 +1019,9 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
             }
             if (live && a.dv) *reinterpret_cast<float4*>(a.dv + r * H + hb) = make_float4(dv4[0], dv4[1], dv4[2], dv4[3]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) hs[j] = half_wave_sum_hi(hs[j]);          // the 32 lanes of this half-wave (equal kh); lanes 16..31 hold it
+            // the 32 lanes of this half-wave (equal kh) on the DPP path, result in lanes 16..31 (as __shfl_xor steps this loop was 640
+            // ds_bpermute_b32 with a wait each: a third of a tile's time)
+            for (int j = 0; j < 4; ++j) hs[j] = half_wave_sum_hi(hs[j]);
             if (l31 == 31) *reinterpret_cast<float4*>(hsum + wave * H + hb) = make_float4(hs[0], hs[1], hs[2], hs[3]);
         }
     }

@@ -744,11 +744,8 @@ __global__ void __launch_bounds__(64 * NW) sddmm_csr_rowblock(const float* __res
                 d[u] = acc;
             }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) d[u] += __shfl_xor(d[u], o, 64);
-            }
-            if (lane == 0) {
+            for (int u = 0; u < 4; ++u) d[u] = wave_sum_hi_dpp(d[u]);       // (DPP path; the total lands in lane 63)
+            if (lane == 63) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (k + NW * u < e) g[ev[u]] = d[u];

@@ -294,10 +294,7 @@ __global__ void __launch_bounds__(kT) reg_bwd_edges(const float* __restrict__ w,
         const float a = x[c], b = yv[c];
         dot = fmaf(a, b, dot); nx = fmaf(a, a, nx); ny = fmaf(b, b, ny);
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {                 // all 16 lanes of a group end with the same sums
-        dot += __shfl_xor(dot, o, 64); nx += __shfl_xor(nx, o, 64); ny += __shfl_xor(ny, o, 64);
-    }
+    dot = row16_sum_all_dpp(dot); nx = row16_sum_all_dpp(nx); ny = row16_sum_all_dpp(ny);      // all 16 lanes of a group end with the same sums
     if (!live) return;
     const float den2 = fmaxf(nx * ny, 1e-16f);
     const float inv = 1.0f / sqrtf(den2);

@@ -104,6 +104,34 @@ __device__ __forceinline__ int wave_sum_int_all(int v) {
     return v;
 }
 
+// The same reductions on the DPP path (no LDS crossbar traffic; __shfl_xor compiles to ds_bpermute_b32 + a wait on this target, which
+// dominated kernels that reduce per edge).  Used where the summation ORDER is free (gradient kernels); the sampler's normalisers keep
+// wave_sum above so that their bits do not move.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+// every lane ends with the sum over its 16-lane row (quad_perm xor 1, xor 2, row_half_mirror, row_mirror)
+__device__ __forceinline__ float row16_sum_all_dpp(float v) {
+    v += dpp_get<0xB1>(v);
+    v += dpp_get<0x4E>(v);
+    v += dpp_get<0x141>(v);
+    v += dpp_get<0x140>(v);
+    return v;
+}
+// sum over each 32-lane half of the wave, valid in lanes 16..31 / 48..63 (row_bcast15 into rows 1 and 3)
+__device__ __forceinline__ float half_wave_sum_hi(float v) {
+    v = row16_sum_all_dpp(v);
+    v += dpp_get<0x142, 0xA>(v);
+    return v;
+}
+// sum over the wave, valid in lane 63 (row_bcast31 into rows 2 and 3 on top)
+__device__ __forceinline__ float wave_sum_hi_dpp(float v) {
+    v = half_wave_sum_hi(v);
+    v += dpp_get<0x143, 0xC>(v);
+    return v;
+}
+
 // Deterministic block sum (fixed tree): result valid in thread 0.  `red` needs blockDim/64 floats.
 __device__ __forceinline__ float block_sum(float v, float* red) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
