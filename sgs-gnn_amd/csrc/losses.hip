@@ -177,21 +177,37 @@ __global__ void __launch_bounds__(kT) reg_fwd_partial(const float* __restrict__ 
                                                      const uint8_t* __restrict__ tm, float* __restrict__ cos_out,
                                                      float* __restrict__ part) {
     __shared__ float red[kT / 64];
-    const int64_t j = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    // 16 lanes per edge (a logits row is C = 41 floats: three 64-byte segments instead of 41 strided scalar loads by one thread), the
+    // workgroup's kT edges in 16 rounds of kT / 16; lane 0 of a group keeps the group's terms
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
     float bce = 0.f, sq = 0.f, nv = 0.f, nl = 0.f;
-    if (j < q) {
-        const int64_t s = sei[j], d = sei[q + j];
-        const float wj = w[j];
-        const float cs = cos_from(edge_dot(logits + s * C, logits + d * C, C));
-        if (cos_out) cos_out[j] = cs;
-        const float df = wj - cs;
-        sq = df * df;
-        if (tm[s] && tm[d]) {
-            nv = 1.f;
-            const bool same = y[s] == y[d];
-            nl = same ? 1.f : 0.f;
-            // F.binary_cross_entropy clamps each log at -100
-            bce = same ? -fmaxf(logf(wj), -100.f) : -fmaxf(logf(1.f - wj), -100.f);
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int64_t j = static_cast<int64_t>(blockIdx.x) * kT + r * (kT / 16) + grp;
+        const bool live = j < q;
+        const int64_t jj = live ? j : 0;
+        const int64_t s = sei[jj], d = sei[q + jj];
+        const float* x = logits + s * C;
+        const float* yv = logits + d * C;
+        float dot = 0.f, nx = 0.f, ny = 0.f;
+        for (int64_t c = sub; c < C; c += 16) {
+            const float a = x[c], b = yv[c];
+            dot = fmaf(a, b, dot); nx = fmaf(a, a, nx); ny = fmaf(b, b, ny);
+        }
+        dot = row16_sum_all_dpp(dot); nx = row16_sum_all_dpp(nx); ny = row16_sum_all_dpp(ny);
+        if (live && sub == 0) {
+            const float wj = w[j];
+            const float cs = cos_from(EdgeTerms{dot, nx, ny});
+            if (cos_out) cos_out[j] = cs;
+            const float df = wj - cs;
+            sq += df * df;
+            if (tm[s] && tm[d]) {
+                nv += 1.f;
+                const bool same = y[s] == y[d];
+                nl += same ? 1.f : 0.f;
+                // F.binary_cross_entropy clamps each log at -100
+                bce += same ? -fmaxf(logf(wj), -100.f) : -fmaxf(logf(1.f - wj), -100.f);
+            }
         }
     }
     const float r0 = block_sum(bce, red);
