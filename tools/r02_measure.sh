@@ -25,6 +25,7 @@ python tools/pmc_summary.py $O/ppmc_sq $O/ppmc_fetch $O/ppmc_write "edge_score_b
 python tools/g1_trace_analyze.py $O/seg > $O/graph_segments_timeline.txt
 python tools/g1_trace.py 2>/dev/null | tail -3 > $O/graph_segment_times.txt          # HIP-event segment times WITHOUT the profiler attached
 cp $O/stats/*/*kernel_stats.csv $O/bench_kernel_stats_whole_process.csv
+python tools/gap_report.py $O/stats 460 > $O/gap_report.txt          # GPU idle time inside the two epochs of the profiled run, by preceding kernel
 # per-kernel totals of the STEPS only: dispatches from the first staging launch on (everything before it builds the synthetic pool)
 python - <<PY
 import csv, glob, collections
