@@ -596,7 +596,9 @@ static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, in
         // partition-sized K: the K-slices are the waves of one workgroup, reduced in LDS, C written in place (any ldc)
         const dim3 grid(cdiv(M, 32), cdiv(N, 32));
         const int64_t ld = ldc > 0 ? ldc : N;
-        if (ks == 8)      hipLaunchKernelGGL((gemm_tn_wg<8>), grid, dim3(512), 0, stream, A, B, K, static_cast<int>(M), static_cast<int>(N), C, ld);
+        if (ks == 8 && K >= 512)      // sixteen 64-row slices: half the dependent load batches per wave (the launch is latency-bound)
+            hipLaunchKernelGGL((gemm_tn_wg<16>), grid, dim3(1024), 0, stream, A, B, K, static_cast<int>(M), static_cast<int>(N), C, ld);
+        else if (ks == 8) hipLaunchKernelGGL((gemm_tn_wg<8>), grid, dim3(512), 0, stream, A, B, K, static_cast<int>(M), static_cast<int>(N), C, ld);
         else if (ks == 4) hipLaunchKernelGGL((gemm_tn_wg<4>), grid, dim3(256), 0, stream, A, B, K, static_cast<int>(M), static_cast<int>(N), C, ld);
         else              hipLaunchKernelGGL((gemm_tn_wg<2>), grid, dim3(128), 0, stream, A, B, K, static_cast<int>(M), static_cast<int>(N), C, ld);
         SGS_LAUNCH_OK();
