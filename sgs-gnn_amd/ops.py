@@ -620,7 +620,7 @@ class _EdgeScore(torch.autograd.Function):
             eid, graph, n = None, get_graph(edge_index, N), E
             gp_act = gp.contiguous()
         f32 = dict(dtype=torch.float32, device=dev)
-        if (_mask_backward and n >= 65536 and N <= 65536 and L.sgs_edge_score_bwd_bits_supported(H) and L.sgs_gemm_tn_mask_supported(n, H, H)
+        if (_mask_backward and n >= 65536 and L.sgs_edge_score_bwd_bits_supported(H) and L.sgs_gemm_tn_mask_supported(n, H, H)
                 and ctx.needs_input_grad[0]):
             return _EdgeScore._backward_mask(ctx, L, codes, U, W1, b1, w2, b2, edge_index, eid, graph, n, gp_act)
         dv, feat = torch.empty(n, H, **f32), torch.empty(n, H, **f32)
@@ -705,13 +705,25 @@ def _edge_score_backward_mask(ctx, L, codes, U, W1, b1, w2, b2, edge_index, eid,
     _lib.check(L.sgs_gemm_tn_mask(_ptr(bits), _ptr(dz), _ptr(w2), scale, _ptr(feat), n, H, H, _ptr(dW1), 2 * H, _ptr(db1), _ptr(db2), wsg.data_ptr(),
                                   wsg.numel(), _stream()), "sgs_gemm_tn_mask")
     dw2 = _colsum(hdz)
+    if N > 65536:                                  # whole graphs (config 5): the wave-per-node reductions; d U from 32 B of mask per entry
+        dcodes = _endpoint_reduce(dfeat, dfeat, codes, graph, 1.0, 1.0, H)
+        dU = torch.empty(N, H, **f32)
+        _lib.check(L.sgs_endpoint_reduce_bits(_ptr(bits), _ptr(dz), _ptr(w2), p, N, H, _ptr(graph.in_ptr), _ptr(graph.in_eid), _ptr(graph.out_ptr),
+                                              _ptr(graph.out_eid), 1.0, -1.0, _ptr(dU), _stream()), "sgs_endpoint_reduce_bits")
+        return _edge_score_backward_mask_tail(L, codes, W1, dcodes, dU, dW1, db1, dw2, db2)
     dcodes = torch.empty(N, H, **f32)
     dU = torch.empty(N, H, **f32)
     _lib.check(L.sgs_endpoint_reduce_pair_bits(_ptr(dfeat), _ptr(bits), _ptr(dz), _ptr(w2), p, _ptr(codes), N, H, graph.n_edges, _ptr(graph.in_ptr),
                                                _ptr(graph.in_src), _ptr(graph.in_eid), _ptr(graph.out_ptr), _ptr(graph.out_dst),
                                                _ptr(graph.out_eid), _ptr(dcodes), _ptr(dU), _stream()), "sgs_endpoint_reduce_pair_bits")
+    return _edge_score_backward_mask_tail(L, codes, W1, dcodes, dU, dW1, db1, dw2, db2)
+
+
+def _edge_score_backward_mask_tail(L, codes, W1, dcodes, dU, dW1, db1, dw2, db2):
+    """The node-level half: U = codes W1b^T  ->  d codes += dU W1b,  d W1b = dU^T codes (right half of d fc1.weight, in place)."""
+    N, H = codes.shape
     dcodes.addmm_(dU, W1[:, H:])
-    wsb = workspace(L.sgs_gemm_tn_workspace_bytes(N, H, H), dev)
+    wsb = workspace(L.sgs_gemm_tn_workspace_bytes(N, H, H), codes.device)
     _lib.check(L.sgs_gemm_tn_ld(_ptr(dU), _ptr(codes), N, H, H, dW1.data_ptr() + 4 * H, 2 * H, None, wsb.data_ptr(), wsb.numel(), _stream()),
                "sgs_gemm_tn_ld")
     return dcodes, dW1, db1, dw2, db2, None, None, None, None, None, None, None

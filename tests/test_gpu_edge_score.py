@@ -122,12 +122,12 @@ def test_production_size_forward_and_active_backward_vs_fp64_oracle(ops, p):
             assert _rel(a.grad, b.grad) < 2e-5, (name, _rel(a.grad, b.grad))
 
 
-@pytest.mark.parametrize("H,p", [(256, 0.3), (128, 0.0), (256, 0.0)])
-def test_mask_backward_equals_dense_backward(ops, H, p):
+@pytest.mark.parametrize("N,H,p", [(777, 256, 0.3), (777, 128, 0.0), (777, 256, 0.0), (70_001, 128, 0.3)])
+def test_mask_backward_equals_dense_backward(ops, N, H, p):
     """The mask form of the backward (one bit per entry of dv; 0 / 1 operands in the two contractions, 3 bf16 products instead of 6)
     against the dense fp32-dv path on the same inputs: the same five gradients to fp32 rounding (they differ only in where the row and
     column factors dz, w2 / (1 - p) are multiplied in)."""
-    N, E, q = 777, 140_000, 66_000
+    E, q = 140_000, 66_000                     # (N > 65 536: the wave-per-node reductions of whole graphs, d U from the mask bits)
     codes, ei, W1, b1, W2, b2, g = _case(N, H, E, 99)
     eid = torch.sort(torch.randperm(E, generator=g)[:q]).values
     gp = torch.zeros(E)
