@@ -275,7 +275,17 @@ __global__ void __launch_bounds__(kT) filter_count_scatter(const int* __restrict
     const int* ptr = out ? out_ptr : in_ptr;
     const int* eid = out ? out_eid : in_eid;
     int c = 0;
-    for (int k = ptr[row] + lane; k < ptr[row + 1]; k += 64) c += mask_at<BITS>(mask, eid[k]) ? 1 : 0;
+    const int b = ptr[row], e = ptr[row + 1];
+    for (int k = b + lane; k < e; k += 256) {          // four entries per lane in flight: ids first, then their mask words
+        int id[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) id[u] = eid[min(k + 64 * u, e - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool m = mask_at<BITS>(mask, id[u]);
+            c += (k + 64 * u < e && m) ? 1 : 0;
+        }
+    }
     c = wave_sum_int_all(c);
     if (lane == 0) (out ? cnt_out : cnt_in)[row] = c;
 }
@@ -300,15 +310,20 @@ __global__ void __launch_bounds__(kT) filter_fill(const int* __restrict__ pin_pt
     int w = (out ? out_ptr : in_ptr)[row];            // write cursor of the child row
     int loop = -1;
     const int b = pptr[row], e = pptr[row + 1];
+    // the next 64 entries' (edge id, column) are loaded while this step's mask / position lookups are in flight, and every load is
+    // unconditional (clamped): as `if (k < e) { pe = ..; sel = mask[pe]; if (sel) { col = ..; ne = pos[pe]; } }` a step was three
+    // dependent memory round trips
+    int pe_c = 0, col_c = 0;
+    if (e > b) { const int kc = min(b + lane, e - 1); pe_c = peid[kc]; col_c = pcol[kc]; }
     for (int k0 = b; k0 < e; k0 += 64) {
         const int k = k0 + lane;
-        int col = 0, ne = 0;
-        bool sel = false;
-        if (k < e) {
-            const int pe = peid[k];
-            sel = mask_at<BITS>(mask, pe);
-            if (sel) { col = pcol[k]; ne = pos[pe]; }
-        }
+        const int kn = min(k + 64, e - 1);
+        const int pe_n = peid[kn], col_n = pcol[kn];
+        const bool m_c = mask_at<BITS>(mask, pe_c);
+        const bool sel = k < e && m_c;
+        const int ne = pos[pe_c];                       // (an unselected edge's slot holds anything: unused)
+        const int col = col_c;
+        pe_c = pe_n; col_c = col_n;
         const unsigned long long bal = __ballot(sel);
         if (sel) {
             const int o = w + __popcll(bal & ((1ull << lane) - 1ull));
