@@ -478,14 +478,18 @@ __global__ void __launch_bounds__(kT) norm_bwd_node(const float* __restrict__ w,
     const int64_t t = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
     if (t >= N) return;
     float acc = 0.f;
-    for (int k = in_ptr[t] + lane; k < in_ptr[t + 1]; k += 64) {
-        const int s = in_src[k];
-        if (s != static_cast<int>(t)) { const int e = in_eid[k]; acc += gw[e] * w[e] * dis[s]; }
-    }
-    for (int k = out_ptr[t] + lane; k < out_ptr[t + 1]; k += 64) {
-        const int d = out_dst[k];
-        if (d != static_cast<int>(t)) { const int e = out_eid[k]; acc += gw[e] * w[e] * dis[d]; }
-    }
+    // (unconditional clamped loads, the condition applied to the finished product: index pair, then the three gathers, per step)
+    auto side = [&](const int* __restrict__ ptr, const int* __restrict__ col, const int* __restrict__ eid) {
+        const int b = ptr[t], e_ = ptr[t + 1];
+        for (int k0 = b; k0 < e_; k0 += 64) {
+            const int k = k0 + lane, kc = min(k, e_ - 1);
+            const int s = col[kc], e = eid[kc];
+            const float v = gw[e] * w[e] * dis[s];
+            if (k < e_ && s != static_cast<int>(t)) acc += v;
+        }
+    };
+    side(in_ptr, in_src, in_eid);
+    side(out_ptr, out_dst, out_eid);
     acc = wave_sum_all(acc);
     if (lane == 0) {
         const float a = dis[t];
