@@ -171,6 +171,10 @@ __device__ __forceinline__ EdgeTerms edge_dot(const float* __restrict__ x, const
 // F.cosine_similarity(x, y, eps=1e-8) = <x,y> / sqrt(max(|x|^2 |y|^2, eps^2))
 __device__ __forceinline__ float cos_from(const EdgeTerms& t) { return t.dot / sqrtf(fmaxf(t.nx * t.ny, 1e-16f)); }
 
+// edges per workgroup of the forward pass: kRegRounds rounds of one edge per 16-lane group (16 rounds measured 28 us at q = 100 000
+// against 19 for the thread-per-edge form: too few workgroups, each a serial chain; 4 rounds: 1 563 workgroups)
+constexpr int kRegRounds = 4;
+constexpr int kRegEdges = kRegRounds * (kT / 16);
 // per block partials: [0]=sum bce, [1]=sum (w-cos)^2, [2]=#valid, [3]=sum labels
 __global__ void __launch_bounds__(kT) reg_fwd_partial(const float* __restrict__ w, const int64_t* __restrict__ sei, int64_t q,
                                                      const float* __restrict__ logits, int64_t C, const int64_t* __restrict__ y,
@@ -178,12 +182,12 @@ __global__ void __launch_bounds__(kT) reg_fwd_partial(const float* __restrict__ 
                                                      float* __restrict__ part) {
     __shared__ float red[kT / 64];
     // 16 lanes per edge (a logits row is C = 41 floats: three 64-byte segments instead of 41 strided scalar loads by one thread), the
-    // workgroup's kT edges in 16 rounds of kT / 16; lane 0 of a group keeps the group's terms
+    // workgroup's kRegEdges edges in kRegRounds rounds of kT / 16; lane 0 of a group keeps the group's terms
     const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
     float bce = 0.f, sq = 0.f, nv = 0.f, nl = 0.f;
-#pragma unroll 4
-    for (int r = 0; r < 16; ++r) {
-        const int64_t j = static_cast<int64_t>(blockIdx.x) * kT + r * (kT / 16) + grp;
+#pragma unroll
+    for (int r = 0; r < kRegRounds; ++r) {
+        const int64_t j = static_cast<int64_t>(blockIdx.x) * kRegEdges + r * (kT / 16) + grp;
         const bool live = j < q;
         const int64_t jj = live ? j : 0;
         const int64_t s = sei[jj], d = sei[q + jj];
@@ -404,7 +408,7 @@ int sgs_masked_ce_bwd(const float* logits, int64_t N, int64_t C, const int64_t* 
     return SGS_OK;
 }
 
-size_t sgs_edge_reg_workspace_bytes(int64_t q) { return carve_bytes(4 * (cdiv(q < 0 ? 0 : q, kT) + 1), 4) + 256; }
+size_t sgs_edge_reg_workspace_bytes(int64_t q) { return carve_bytes(4 * (cdiv(q < 0 ? 0 : q, kRegEdges) + 1), 4) + 256; }
 
 int sgs_edge_reg_fwd(const float* w, const int64_t* sampled_edge_index, int64_t q, const float* logits, int64_t N, int64_t C,
                      const int64_t* y, const uint8_t* train_mask, float coef1, float coef2, float* out, float* cos_out,
@@ -414,7 +418,7 @@ int sgs_edge_reg_fwd(const float* w, const int64_t* sampled_edge_index, int64_t 
                 "sgs_edge_reg_fwd: bad arguments");
     SGS_REQUIRE(ws && ws_bytes >= sgs_edge_reg_workspace_bytes(q), SGS_EWORKSPACE, "sgs_edge_reg_fwd: workspace too small");
     Carver cv(ws);
-    const int64_t nblk = cdiv(q, kT);
+    const int64_t nblk = cdiv(q, kRegEdges);
     float* part = cv.take<float>(4 * (nblk + 1));
     hipLaunchKernelGGL(reg_fwd_partial, dim3(nblk), dim3(kT), 0, stream, w, sampled_edge_index, q, logits, C, y, train_mask, cos_out,
                        part);
@@ -432,7 +436,7 @@ int sgs_hybrid_loss_fwd(const float* logits, int64_t N, int64_t C, const int64_t
                 SGS_EINVAL, "sgs_hybrid_loss_fwd: bad arguments");
     SGS_REQUIRE(ws && ws_bytes >= sgs_edge_reg_workspace_bytes(q), SGS_EWORKSPACE, "sgs_hybrid_loss_fwd: workspace too small");
     Carver cv(ws);
-    const int64_t nblk = cdiv(q, kT);
+    const int64_t nblk = cdiv(q, kRegEdges);
     float* part = cv.take<float>(4 * (nblk + 1));
     hipLaunchKernelGGL(ce_rows, dim3(cdiv(N * 64, kT)), dim3(kT), 0, stream, logits, N, C, y, train_mask, row_lse, rowloss);
     hipLaunchKernelGGL(reg_fwd_partial, dim3(nblk), dim3(kT), 0, stream, w, sampled_edge_index, q, logits, C, y, train_mask,
@@ -459,7 +463,7 @@ int sgs_edge_reg_partial(const float* w, const int64_t* sampled_edge_index, int6
     SGS_REQUIRE(q >= 0 && N > 0 && C > 0 && raw, SGS_EINVAL, "sgs_edge_reg_partial: bad arguments");
     SGS_REQUIRE(ws && ws_bytes >= sgs_edge_reg_workspace_bytes(q), SGS_EWORKSPACE, "sgs_edge_reg_partial: workspace too small");
     Carver cv(ws);
-    const int64_t nblk = cdiv(q, kT);
+    const int64_t nblk = cdiv(q, kRegEdges);
     float* part = cv.take<float>(4 * (nblk + 1));
     if (q > 0) {
         SGS_REQUIRE(w && sampled_edge_index && logits && y && train_mask, SGS_EINVAL, "sgs_edge_reg_partial: null pointer");
