@@ -59,7 +59,7 @@ constexpr int kWgUnroll = 8;              // k2-steps in flight per wave (16 mea
 template <int NW>
 __global__ void __launch_bounds__(64 * NW) gemm_tn_wg(const float* __restrict__ A, const float* __restrict__ B, int64_t K, int M, int N,
                                                      float* __restrict__ C, int64_t ldc) {
-    __shared__ float red[NW / 2][16][64];
+    __shared__ float red[NW][16][64];                                       // every wave's partial tile: 4 KB each
     const int lane = threadIdx.x & 63, s = threadIdx.x >> 6, kh = lane >> 5, l31 = lane & 31;
     const int ti = blockIdx.x, tj = blockIdx.y;
     const int i = ti * 32 + l31, j = tj * 32 + l31;
@@ -87,24 +87,22 @@ __global__ void __launch_bounds__(64 * NW) gemm_tn_wg(const float* __restrict__ 
         const float b = (jok && kk < k1) ? B[kk * N + j] : 0.f;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
+    // ONE barrier: every wave parks its tile, then wave s sums accumulator registers s * 16/NW .. of all slices in slice order (fixed) and
+    // writes those rows of C -- the combine and the store are spread over the workgroup (a halving tree cost 2 log2(NW) barriers and left
+    // the store to wave 0)
 #pragma unroll
-    for (int half = NW / 2; half >= 1; half >>= 1) {                       // upper half stores, lower half adds, halve, repeat
-        if (s >= half && s < 2 * half) {
+    for (int r = 0; r < 16; ++r) red[s][r][lane] = acc[r];
+    __syncthreads();
+    if (!jok) return;
+    constexpr int RPW = 16 / NW;                                            // accumulator registers finished by a wave
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[s - half][r][lane] = acc[r];
-        }
-        __syncthreads();
-        if (s < half) {
+    for (int q = 0; q < RPW; ++q) {
+        const int r = s * RPW + q;
+        float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += red[s][r][lane];
-        }
-        __syncthreads();
-    }
-    if (s != 0 || !jok) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
+        for (int z = 0; z < NW; ++z) sum += red[z][r][lane];
         const int row = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (row < M) C[static_cast<int64_t>(row) * ldc + j] = acc[r];
+        if (row < M) C[static_cast<int64_t>(row) * ldc + j] = sum;
     }
 }
 
