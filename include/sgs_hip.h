@@ -378,11 +378,6 @@ int sgs_endpoint_reduce_pair_bits(const float* dfeat, const uint32_t* dvbits, co
                                   int64_t N, int64_t H, int64_t nnz, const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid,
                                   const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid, float* out_codes, float* out_U,
                                   sgs_stream_t stream);
-/* d U alone, for graphs the row-block kernels do not serve (N > 65 536): out[v, :] = w2 / (1 - p) * (sign_out * sum_{out-row of v} +
- * sign_in * sum_{in-row of v}) dz[e] bits[e, :]  (one wave per node; H % 32 == 0). */
-int sgs_endpoint_reduce_bits(const uint32_t* dvbits, const float* dz, const float* w2, float p_drop, int64_t N, int64_t H, const int32_t* in_ptr,
-                             const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_eid, float sign_out, float sign_in, float* out,
-                             sgs_stream_t stream);
 /* C[M, N] (row stride ldc) = (diag(dz) mask diag(rowscale * scale))^T B, mask bits [K, M/32]; colsum_A (optional, [M]) = that matrix's column
  * sums; dz_sum (optional, [1]) = sum_k dz[k] (d fc2.bias rides along).  Tall-K shapes only (sgs_gemm_tn_mask_supported);
  * ws: sgs_gemm_tn_workspace_bytes(K, M, N). */

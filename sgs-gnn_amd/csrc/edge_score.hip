@@ -1281,51 +1281,6 @@ __global__ void __launch_bounds__(64 * NW) endpoint_reduce_rowblock(const float*
     }
 }
 
-// out[v, c] = w2[c] * scale * (sgn_out * sum_{out-row} + sgn_in * sum_{in-row}) dz[e] * bit[e, c]: the d U reduction of the mask-form
-// backward for graphs the row-block kernels do not serve (N > 65 536; config 5): one wave per node, four entries in flight, 32 B of mask
-// per entry where the dense form gathers a 1 KB row of dv.
-__global__ void __launch_bounds__(kT) endpoint_reduce_bits(const uint32_t* __restrict__ bits, const float* __restrict__ dz,
-                                                          const float* __restrict__ w2, float scale, int64_t N, int64_t H,
-                                                          const int* __restrict__ in_ptr, const int* __restrict__ in_eid,
-                                                          const int* __restrict__ out_ptr, const int* __restrict__ out_eid, float sgn_out,
-                                                          float sgn_in, float* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t v = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;   // one wave per node
-    if (v >= N) return;
-    const int wpr = static_cast<int>(H >> 5);
-    for (int64_t c0 = static_cast<int64_t>(lane) * 4; c0 < H; c0 += 256) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int dir = 0; dir < 2; ++dir) {
-            const int* ptr = dir == 0 ? out_ptr : in_ptr;
-            const int* eid = dir == 0 ? out_eid : in_eid;
-            const float sg = dir == 0 ? sgn_out : sgn_in;
-            const int b = ptr[v], e = ptr[v + 1];
-            for (int k = b; k < e; k += 4) {
-                int er[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) er[u] = eid[k + u < e ? k + u : e - 1];
-                uint32_t wd[4];
-                float dzr[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    wd[u] = bits[static_cast<int64_t>(er[u]) * wpr + (c0 >> 5)];
-                    dzr[u] = dz[er[u]];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float a = k + u < e ? sg * dzr[u] : 0.f;
-                    const uint32_t w = wd[u] >> (c0 & 31);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j] += (w >> j) & 1u ? a : 0.f;
-                }
-            }
-        }
-        const float4 ww = *reinterpret_cast<const float4*>(w2 + c0);
-        *reinterpret_cast<float4*>(out + v * H + c0) = make_float4(acc[0] * (ww.x * scale), acc[1] * (ww.y * scale), acc[2] * (ww.z * scale),
-                                                                   acc[3] * (ww.w * scale));
-    }
-}
-
 // The scorer backward's two endpoint reductions in ONE pass over the incident-edge lists of a node v:
 //   out_codes[v,:] = sum_k dfeat[e_k,:] * codes[other_k,:]          (both orientations, sign +)
 //   out_U[v,:]     = sum_{k in out-row} dv[e_k,:] - sum_{k in in-row} dv[e_k,:]
@@ -1784,7 +1739,7 @@ int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, i
                     (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
                     (!T || (reinterpret_cast<uintptr_t>(T) & 15) == 0);
     const dim3 blk(kT);
-    if (N <= 65536 && nnz >= 8 * N) {         // few, long rows: a workgroup per node
+    if (nnz >= 8 * N) {                       // long rows: a workgroup per node (partitions, and whole graphs of average degree >= 8)
         const dim3 grid(static_cast<unsigned>(N));
         const bool wide = nnz >= 64 * N;       // long rows (hubs with thousands of entries): 16 waves per node
 #define SGS_EPR(VEC_, HT_)                                                                                                   \
@@ -1816,7 +1771,7 @@ int sgs_endpoint_reduce_pair(const float* dfeat, const float* dv, const float* c
                              const int32_t* in_src, const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_dst,
                              const int32_t* out_eid, float* out_codes, float* out_U, sgs_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    SGS_REQUIRE(N >= 0 && H >= 0 && H % 4 == 0 && N <= 65536, SGS_EINVAL, "sgs_endpoint_reduce_pair: needs H %% 4 == 0 and N <= 65536");
+    SGS_REQUIRE(N >= 0 && H >= 0 && H % 4 == 0 && N < (int64_t(1) << 31), SGS_EINVAL, "sgs_endpoint_reduce_pair: needs H %% 4 == 0");
     if (N == 0 || H == 0) return SGS_OK;
     SGS_REQUIRE(dfeat && dv && codes && in_ptr && out_ptr && out_codes && out_U, SGS_EINVAL, "sgs_endpoint_reduce_pair: null pointer");
     const dim3 grid(static_cast<unsigned>(N));
@@ -1830,26 +1785,13 @@ int sgs_endpoint_reduce_pair(const float* dfeat, const float* dv, const float* c
     return SGS_OK;
 }
 
-int sgs_endpoint_reduce_bits(const uint32_t* dvbits, const float* dz, const float* w2, float p_drop, int64_t N, int64_t H, const int32_t* in_ptr,
-                             const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_eid, float sign_out, float sign_in, float* out,
-                             sgs_stream_t stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    SGS_REQUIRE(N >= 0 && H >= 0 && H % 32 == 0 && p_drop >= 0.f && p_drop < 1.f, SGS_EINVAL, "sgs_endpoint_reduce_bits: needs H %% 32 == 0");
-    if (N == 0 || H == 0) return SGS_OK;
-    SGS_REQUIRE(dvbits && dz && w2 && in_ptr && in_eid && out_ptr && out_eid && out, SGS_EINVAL, "sgs_endpoint_reduce_bits: null pointer");
-    hipLaunchKernelGGL(endpoint_reduce_bits, dim3(static_cast<unsigned>(cdiv(N * 64, kT))), dim3(kT), 0, stream, dvbits, dz, w2,
-                       1.0f / (1.0f - p_drop), N, H, in_ptr, in_eid, out_ptr, out_eid, sign_out, sign_in, out);
-    SGS_LAUNCH_OK();
-    return SGS_OK;
-}
-
 int sgs_endpoint_reduce_pair_bits(const float* dfeat, const uint32_t* dvbits, const float* dz, const float* w2, float p_drop, const float* codes,
                                   int64_t N, int64_t H, int64_t nnz, const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid,
                                   const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid, float* out_codes, float* out_U,
                                   sgs_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    SGS_REQUIRE(N >= 0 && H >= 0 && H % 32 == 0 && N <= 65536 && p_drop >= 0.f && p_drop < 1.f, SGS_EINVAL,
-                "sgs_endpoint_reduce_pair_bits: needs H %% 32 == 0 and N <= 65536");
+    SGS_REQUIRE(N >= 0 && H >= 0 && H % 32 == 0 && N < (int64_t(1) << 31) && p_drop >= 0.f && p_drop < 1.f, SGS_EINVAL,
+                "sgs_endpoint_reduce_pair_bits: needs H %% 32 == 0");
     if (N == 0 || H == 0) return SGS_OK;
     SGS_REQUIRE(dfeat && dvbits && dz && w2 && codes && in_ptr && out_ptr && out_codes && out_U, SGS_EINVAL,
                 "sgs_endpoint_reduce_pair_bits: null pointer");

@@ -310,8 +310,8 @@ __global__ void __launch_bounds__(kT) filter_fill(const int* __restrict__ pin_pt
     int w = (out ? out_ptr : in_ptr)[row];            // write cursor of the child row
     int loop = -1;
     const int b = pptr[row], e = pptr[row + 1];
-    // the next 64 entries' (edge id, column) are loaded while this step's mask / position lookups are in flight, and every load is
-    // unconditional (clamped): as `if (k < e) { pe = ..; sel = mask[pe]; if (sel) { col = ..; ne = pos[pe]; } }` a step was three
+    // the next 64 entries' (edge id, column) are loaded while this step's mask / position lookups are in flight, and the id / column / mask
+    // loads are unconditional (clamped): as `if (k < e) { pe = ..; sel = mask[pe]; if (sel) { col = ..; ne = pos[pe]; } }` a step was three
     // dependent memory round trips
     int pe_c = 0, col_c = 0;
     if (e > b) { const int kc = min(b + lane, e - 1); pe_c = peid[kc]; col_c = pcol[kc]; }
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(kT) filter_fill(const int* __restrict__ pin_pt
         const int pe_n = peid[kn], col_n = pcol[kn];
         const bool m_c = mask_at<BITS>(mask, pe_c);
         const bool sel = k < e && m_c;
-        const int ne = pos[pe_c];                       // (an unselected edge's slot holds anything: unused)
+        const int ne = sel ? pos[pe_c] : 0;             // selected entries only: on a whole graph `pos` is hundreds of MB of random 4-byte reads
         const int col = col_c;
         pe_c = pe_n; col_c = col_n;
         const unsigned long long bal = __ballot(sel);
@@ -1268,7 +1268,7 @@ int sgs_sddmm_csr(const float* A, const float* B, int64_t N, int64_t D, int64_t 
     SGS_REQUIRE(A && B && ptr, SGS_EINVAL, "sgs_sddmm_csr: null pointer");
     const int vec = (D % 4 == 0 && aligned16(A) && aligned16(B)) ? 4 : 1;
     const int lpr = pick_lpr(D, vec);
-    if (N <= 65536 && nnz >= 16 * N) {
+    if (nnz >= 16 * N) {                      // long rows (partitions; whole graphs of average degree >= 16): a workgroup per row
         const bool wide = nnz >= 64 * N;
         const dim3 g_(static_cast<unsigned>(N));
         if (vec == 4 && wide) hipLaunchKernelGGL((sddmm_csr_rowblock<4, 16>), g_, dim3(1024), 0, stream, A, B, N, D, ptr, col, eid, g, gdiag);

@@ -657,7 +657,7 @@ class _EdgeScore(torch.autograd.Function):
             db1 = _colsum(dv)
         dw2 = _colsum(hdz)
         db2 = _colsum(dz.view(n, 1)).reshape(1)
-        if H % 4 == 0 and N <= 65536:                          # both endpoint reductions in one pass over the incident-edge lists
+        if H % 4 == 0:                                         # both endpoint reductions in one pass over the incident-edge lists
             dcodes = torch.empty(N, H, dtype=torch.float32, device=dev)
             dU = torch.empty(N, H, dtype=torch.float32, device=dev)
             _lib.check(L.sgs_endpoint_reduce_pair(_ptr(dfeat), _ptr(dv), _ptr(codes), N, H, graph.n_edges, _ptr(graph.in_ptr), _ptr(graph.in_src),
@@ -705,12 +705,6 @@ def _edge_score_backward_mask(ctx, L, codes, U, W1, b1, w2, b2, edge_index, eid,
     _lib.check(L.sgs_gemm_tn_mask(_ptr(bits), _ptr(dz), _ptr(w2), scale, _ptr(feat), n, H, H, _ptr(dW1), 2 * H, _ptr(db1), _ptr(db2), wsg.data_ptr(),
                                   wsg.numel(), _stream()), "sgs_gemm_tn_mask")
     dw2 = _colsum(hdz)
-    if N > 65536:                                  # whole graphs (config 5): the wave-per-node reductions; d U from 32 B of mask per entry
-        dcodes = _endpoint_reduce(dfeat, dfeat, codes, graph, 1.0, 1.0, H)
-        dU = torch.empty(N, H, **f32)
-        _lib.check(L.sgs_endpoint_reduce_bits(_ptr(bits), _ptr(dz), _ptr(w2), p, N, H, _ptr(graph.in_ptr), _ptr(graph.in_eid), _ptr(graph.out_ptr),
-                                              _ptr(graph.out_eid), 1.0, -1.0, _ptr(dU), _stream()), "sgs_endpoint_reduce_bits")
-        return _edge_score_backward_mask_tail(L, codes, W1, dcodes, dU, dW1, db1, dw2, db2)
     dcodes = torch.empty(N, H, **f32)
     dU = torch.empty(N, H, **f32)
     _lib.check(L.sgs_endpoint_reduce_pair_bits(_ptr(dfeat), _ptr(bits), _ptr(dz), _ptr(w2), p, _ptr(codes), N, H, graph.n_edges, _ptr(graph.in_ptr),
