@@ -1,5 +1,6 @@
+"""HIP-event time of one learned draw (ops.sample_topq, fused small-E path) at the bench partition's size: python tools/samp_probe.py"""
 import sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
 import sgs_gnn_amd as S
 from sgs_gnn_amd import ops
 dev = torch.device("cuda:0")
