@@ -318,6 +318,8 @@ int sgs_act_bwd_colsum(const float* dY, const float* Y, int64_t N, int64_t D, in
  *   d codes (direct) = reduce(dfeat, dfeat, T = codes, +1, +1);   d U = reduce(dv, dv, NULL, +1, -1).
  * ---------------------------------------------------------------------------------- */
 size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H, int64_t E);   /* E = 0 for the backward core */
+int sgs_edge_score_get_variant(void);          /* the overrides currently set (-1 = automatic) */
+int sgs_edge_score_get_bwd_variant(void);
 void sgs_edge_score_set_bwd_variant(int variant); /* backward core: -1 = automatic (4 at H % 128 == 0 and >= 65 536 active rows, else 0), 0 = LDS-tiled, 3 = 64-edge streaming loop (A/B: measured slower), 4 = bf16x6 loop */
 int sgs_edge_score_bwd_tile(void);              /* active rows per hdz_part row (64) */
 void sgs_edge_score_set_variant(int variant);   /* forward kernel: -1 = automatic (default: when E >= 65 536, 4 if H % 128 == 0 else 3; below that 1),
@@ -368,6 +370,23 @@ int sgs_edge_score_bwd_dfeat(const float* dv, int64_t n, int64_t H, const float*
  * A 0 / 1 operand is exact in bf16: the two contractions issue 3 bf16 MFMA products per fp32 product (the other operand's exact 3-way
  * split) instead of 6, still fp32-faithful.  Other arguments as sgs_edge_score_bwd_core / _bwd_dfeat / sgs_endpoint_reduce_pair. */
 int sgs_edge_score_bwd_bits_supported(int64_t H);
+/* No recompute at all when the FORWARD kept the mask (sgs_edge_score_fwd_mask: the bf16x6 forward, paired when canon / mate are given, that
+ * also writes maskbits [E, H/32] for every scored edge; scores bit-identical to the plain forward):
+ *   sgs_edge_score_bwd_prep        per active row r (edge e): dz[r] = grad_p[r] p[e] (1 - p[e]), dvbits[r, :] = maskbits[e, :],
+ *                                  feat[r, :] = codes[src e, :] * codes[dst e, :]                       (one HBM-bound pass)
+ *   sgs_edge_score_dw2_from_parts  d fc2.weight[h] = 1/(1-p) * ( sum_k W1a[h,k] T[h,k] + sum_v U[v,h] R[v,h] + b1[h] c[h] ) from the
+ *                                  consumers' results before their factors: T = C_raw and c = colsum_raw of sgs_gemm_tn_mask,
+ *                                  R = out_U_raw of sgs_endpoint_reduce_pair_bits (exact algebra: hidden = mask * (W1a feat + U[s] - U[d] + b1) / (1-p))
+ * then sgs_edge_score_bwd_dfeat_bits, sgs_gemm_tn_mask, sgs_endpoint_reduce_pair_bits as after sgs_edge_score_bwd_core_bits. */
+int sgs_edge_score_fwd_mask(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
+                            int64_t edge_id_offset, const int32_t* canon, int64_t M, const int32_t* mate, const float* W1, const float* b1,
+                            const float* w2, const float* b2, float p_drop, uint64_t seed, uint32_t site, float* p_out, uint32_t* maskbits,
+                            void* ws, size_t ws_bytes, sgs_stream_t stream);
+int sgs_edge_score_bwd_prep(const float* codes, int64_t N, int64_t H, const int64_t* edge_index, int64_t E, const int64_t* active_eid,
+                            int64_t n_active, const float* grad_p, const float* p, const uint32_t* maskbits, float* dz, uint32_t* dvbits,
+                            float* feat, sgs_stream_t stream);
+int sgs_edge_score_dw2_from_parts(const float* W1, const float* T_raw, const float* U, const float* R_raw, const float* b1, const float* c_raw,
+                                  int64_t N, int64_t H, float p_drop, float* dw2, sgs_stream_t stream);
 int sgs_edge_score_bwd_core_bits(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
                                  int64_t edge_id_offset, const int64_t* active_eid, int64_t n_active, const float* grad_p, const float* W1,
                                  const float* b1, const float* w2, const float* b2, float p_drop, uint64_t seed, uint32_t site,
@@ -377,13 +396,15 @@ int sgs_edge_score_bwd_dfeat_bits(const uint32_t* dvbits, const float* dz, int64
 int sgs_endpoint_reduce_pair_bits(const float* dfeat, const uint32_t* dvbits, const float* dz, const float* w2, float p_drop, const float* codes,
                                   int64_t N, int64_t H, int64_t nnz, const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid,
                                   const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid, float* out_codes, float* out_U,
-                                  sgs_stream_t stream);
+                                  float* out_U_raw, sgs_stream_t stream);
 /* C[M, N] (row stride ldc) = (diag(dz) mask diag(rowscale * scale))^T B, mask bits [K, M/32]; colsum_A (optional, [M]) = that matrix's column
- * sums; dz_sum (optional, [1]) = sum_k dz[k] (d fc2.bias rides along).  Tall-K shapes only (sgs_gemm_tn_mask_supported);
+ * sums; dz_sum (optional, [1]) = sum_k dz[k] (d fc2.bias rides along); C_raw [M, N] / colsum_raw [M] (optional): the same two results
+ * before the factor rowscale * scale (terms of d fc2.weight, sgs_edge_score_dw2_from_parts).  Tall-K shapes only (sgs_gemm_tn_mask_supported);
  * ws: sgs_gemm_tn_workspace_bytes(K, M, N). */
 int sgs_gemm_tn_mask_supported(int64_t K, int64_t M, int64_t N);
 int sgs_gemm_tn_mask(const uint32_t* Abits, const float* dz, const float* rowscale, float scale, const float* B, int64_t K, int64_t M, int64_t N,
-                     float* C, int64_t ldc, float* colsum_A, float* dz_sum, void* ws, size_t ws_bytes, sgs_stream_t stream);
+                     float* C, int64_t ldc, float* colsum_A, float* dz_sum, float* C_raw, float* colsum_raw, void* ws, size_t ws_bytes,
+                     sgs_stream_t stream);
 
 int sgs_endpoint_reduce(const float* M_out, const float* M_in, const float* T, int64_t N, int64_t H, int64_t nnz,
                         const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid, const int32_t* out_ptr,

@@ -919,6 +919,14 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
         ud[i] = *reinterpret_cast<const float4*>(Ud + 8 * i);
     }
     float z = 0.f;
+    // forward with `dvbits`: the ReLU x dropout mask of every scored edge, one bit per hidden unit (bit h of edge e in word h / 32 of row e)
+    // -- with it the backward needs no recompute for dz and dv (sgs_edge_score_fwd_mask)
+    const bool want_bits = !BWD && a.dvbits != nullptr;
+    uint32_t fb[NT], fb2[PAIR ? NT : 1];             // whole rows in registers, two 16-byte stores per row at the end
+#pragma unroll
+    for (int t = 0; t < NT; ++t) fb[t] = 0u;
+#pragma unroll
+    for (int t = 0; t < (PAIR ? NT : 1); ++t) fb2[t] = 0u;
 #pragma unroll
     for (int i = 0; i < 4 * NT; ++i) {
         if (8 * i < Hrt) {                           // always true: one basic block per step keeps the look-ahead at kPF steps
@@ -956,6 +964,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
                         m2 = draw2 >= a.drop_thresh ? m2 * a.drop_scale : 0.f;
                     }
                     z2 = fmaf(w4[j], v2 * m2, z2);
+                    if (want_bits) fb2[PAIR ? t : 0] |= min(__float_as_uint(m2), 1u) << (8 * g4 + j);      // m2 is +0.0 or a positive factor
                 }
             }
 #pragma unroll
@@ -969,6 +978,27 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
                 const float hd = v * m;                              // dropout(relu(v))
                 z = fmaf(w4[j], hd, z);
                 if (BWD) acc[t][4 * g4 + j] = hd;                    // kept for the second pass
+                // the factor m is +0.0 (v <= 0 or dropped) or positive: its bit pattern is nonzero exactly where hd > 0 (hd itself may be -0.0).
+                // Compile-time positions; the kh nibble shift is applied once per word below
+                if (want_bits) fb[t] |= min(__float_as_uint(m), 1u) << (8 * g4 + j);
+            }
+        }
+    }
+    if (want_bits) {                                                 // join the two kh halves of every word, one lane stores the row
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { fb[t] <<= 4 * kh; fb[t] |= __shfl_xor(fb[t], 32, 64); }
+        if (live && kh == 0) {
+            uint4* bo = reinterpret_cast<uint4*>(a.dvbits + eg_id * NT);
+#pragma unroll
+            for (int t = 0; t < NT; t += 4) bo[t >> 2] = make_uint4(fb[t], fb[t + 1], fb[t + 2], fb[t + 3]);
+        }
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { fb2[t] <<= 4 * kh; fb2[t] |= __shfl_xor(fb2[t], 32, 64); }
+            if (live && kh == 0 && mate_id >= 0) {
+                uint4* bo = reinterpret_cast<uint4*>(a.dvbits + mate_id * NT);
+#pragma unroll
+                for (int t = 0; t < NT; t += 4) bo[t >> 2] = make_uint4(fb2[t], fb2[t + 1], fb2[t + 2], fb2[t + 3]);
             }
         }
     }
@@ -1281,6 +1311,65 @@ __global__ void __launch_bounds__(64 * NW) endpoint_reduce_rowblock(const float*
     }
 }
 
+// The backward WITHOUT a recompute (the forward kept the mask: sgs_edge_score_fwd_mask).  Per active row r (edge e = active[r]):
+//   dz[r] = gp[r] p[e] (1 - p[e]),   bits[r, :] = maskbits[e, :],   feat[r, :] = codes[src e, :] * codes[dst e, :]
+// -- everything the three consumers of the mask form need, in one HBM-bound pass (the feat rows are the bytes: 4 H per row).
+__global__ void __launch_bounds__(kT) scorer_bwd_prep(const float* __restrict__ codes, int64_t H, const int64_t* __restrict__ src,
+                                                     const int64_t* __restrict__ dst, const int64_t* __restrict__ active, int64_t n,
+                                                     const float* __restrict__ gp, const float* __restrict__ p,
+                                                     const uint32_t* __restrict__ maskbits, float* __restrict__ dz,
+                                                     uint32_t* __restrict__ bits, float* __restrict__ feat) {
+    constexpr int R = 4;                                                  // rows per wave: their index chains and gathers in flight together
+    const int lane = threadIdx.x & 63;
+    const int64_t r0 = ((static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6) * R;
+    if (r0 >= n) return;
+    const int wpr = static_cast<int>(H >> 5);
+    int64_t e[R], s[R], d[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const int64_t r = r0 + u < n ? r0 + u : n - 1;                    // (rows past the end: the last row again, not stored)
+        e[u] = active ? active[r] : r;
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) { s[u] = src[e[u]]; d[u] = dst[e[u]]; }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        if (r0 + u >= n) break;
+        if (lane < wpr) bits[(r0 + u) * wpr + lane] = maskbits[e[u] * wpr + lane];
+        if (lane == 63) { const float pe = p[e[u]]; dz[r0 + u] = gp[r0 + u] * pe * (1.0f - pe); }
+    }
+    for (int64_t c0 = static_cast<int64_t>(lane) * 4; c0 < H; c0 += 256) {
+        float4 a[R], b[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            a[u] = *reinterpret_cast<const float4*>(codes + s[u] * H + c0);
+            b[u] = *reinterpret_cast<const float4*>(codes + d[u] * H + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+            if (r0 + u < n)
+                *reinterpret_cast<float4*>(feat + (r0 + u) * H + c0) = make_float4(a[u].x * b[u].x, a[u].y * b[u].y, a[u].z * b[u].z, a[u].w * b[u].w);
+    }
+}
+
+// d fc2.weight without the hidden activations: hd[e, h] = bit[e, h] * scale * (W1a feat_e + U[s] - U[d] + b1)[h], so
+//   dw2[h] = sum_e dz_e hd[e, h] = scale * ( sum_k W1a[h, k] T[h, k]  +  sum_v U[v, h] R[v, h]  +  b1[h] c[h] )
+// with T = mask^T diag(dz) feat (the weight-gradient GEMM before its row factor), R[v, :] = (sum_out - sum_in) dz_e bit[e, :] (the d U
+// reduction before its column factor) and c = mask^T dz (the column sums before theirs).  One workgroup per hidden unit.
+__global__ void __launch_bounds__(kT) scorer_dw2_from_parts(const float* __restrict__ W1, const float* __restrict__ Traw, const float* __restrict__ U,
+                                                           const float* __restrict__ Rraw, const float* __restrict__ b1,
+                                                           const float* __restrict__ craw, int64_t N, int H, float scale,
+                                                           float* __restrict__ dw2) {
+    __shared__ float red[kT / 64];
+    const int h = blockIdx.x;
+    float a = 0.f, b = 0.f;
+    for (int k = threadIdx.x; k < H; k += kT) a = fmaf(W1[static_cast<int64_t>(h) * 2 * H + k], Traw[static_cast<int64_t>(h) * H + k], a);
+    for (int64_t v = threadIdx.x; v < N; v += kT) b = fmaf(U[v * H + h], Rraw[v * H + h], b);
+    const float ra = block_sum(a, red);
+    const float rb = block_sum(b, red);
+    if (threadIdx.x == 0) dw2[h] = scale * ((ra + rb) + b1[h] * craw[h]);
+}
+
 // The scorer backward's two endpoint reductions in ONE pass over the incident-edge lists of a node v:
 //   out_codes[v,:] = sum_k dfeat[e_k,:] * codes[other_k,:]          (both orientations, sign +)
 //   out_U[v,:]     = sum_{k in out-row} dv[e_k,:] - sum_{k in in-row} dv[e_k,:]
@@ -1297,7 +1386,8 @@ __global__ void __launch_bounds__(64 * NW) endpoint_reduce_pair_rowblock(const f
                                                                         float* __restrict__ out_codes, float* __restrict__ out_U,
                                                                         const uint32_t* __restrict__ bits = nullptr,
                                                                         const float* __restrict__ dz = nullptr,
-                                                                        const float* __restrict__ w2 = nullptr, float scale = 1.f) {
+                                                                        const float* __restrict__ w2 = nullptr, float scale = 1.f,
+                                                                        float* __restrict__ out_Uraw = nullptr) {
     __shared__ float part[2][NW][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t v = blockIdx.x;
@@ -1363,7 +1453,10 @@ __global__ void __launch_bounds__(64 * NW) endpoint_reduce_pair_rowblock(const f
                 float sum = 0.f;
 #pragma unroll
                 for (int g = 0; g < NW; g += 4) sum += (part[which][g][c] + part[which][g + 1][c]) + (part[which][g + 2][c] + part[which][g + 3][c]);
-                if (BITS && which) sum *= w2[cbase + c] * scale;
+                if (BITS && which) {
+                    if (out_Uraw) out_Uraw[v * H + cbase + c] = sum;      // before the column factor: a term of d fc2.weight (scorer_dw2_from_parts)
+                    sum *= w2[cbase + c] * scale;
+                }
                 (which ? out_U : out_codes)[v * H + cbase + c] = sum;
             }
         }
@@ -1433,6 +1526,8 @@ static int g_bwd_variant = -1;     // -1: automatic (4 at H % 128 == 0 and >= 65
 static int g_score_variant = -1;   // -1: automatic (when the launch fills the chip with 128-edge workgroups: 4 if H % 128 == 0, else 3; otherwise 1)
 void sgs_edge_score_set_variant(int v) { g_score_variant = v; }
 void sgs_edge_score_set_bwd_variant(int v) { g_bwd_variant = v; }
+int sgs_edge_score_get_variant(void) { return g_score_variant; }
+int sgs_edge_score_get_bwd_variant(void) { return g_bwd_variant; }
 int sgs_edge_score_bwd_tile(void) { return kBM; }
 
 int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
@@ -1534,16 +1629,43 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
 /* Paired forward (sgs_hip.h): only the `M` canonical edges run the H x H contraction; each also finishes its mate's score. */
 int sgs_edge_score_paired_supported(int64_t H) { return (H == 128 || H == 256) ? 1 : 0; }
 
+static int fwd_bf16x6_impl(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
+                           int64_t edge_id_offset, const int32_t* canon, int64_t M, const int32_t* mate, const float* W1, const float* b1,
+                           const float* w2, const float* b2, float p_drop, uint64_t seed, uint32_t site, float* p_out, uint32_t* maskbits,
+                           void* ws, size_t ws_bytes, sgs_stream_t stream_);
+
 int sgs_edge_score_fwd_paired(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
                               int64_t edge_id_offset, const int32_t* canon, int64_t M, const int32_t* mate, const float* W1, const float* b1,
                               const float* w2, const float* b2, float p_drop, uint64_t seed, uint32_t site, float* p_out, void* ws,
                               size_t ws_bytes, sgs_stream_t stream_) {
+    SGS_REQUIRE((canon && mate) || E == 0 || M == 0, SGS_EINVAL, "sgs_edge_score_fwd_paired: null pointer");
+    return fwd_bf16x6_impl(codes, U, N, H, edge_index, E, edge_id_offset, canon, M, mate, W1, b1, w2, b2, p_drop, seed, site, p_out, nullptr, ws,
+                           ws_bytes, stream_);
+}
+
+/* The bf16x6 forward (paired when canon / mate are given, every edge otherwise) that also writes the ReLU x dropout MASK of every scored
+ * edge: maskbits [E, H/32], bit h of edge e in word h / 32 of row e.  With the mask and p the backward needs no recompute for dz and dv
+ * (sgs_edge_score_bwd_prep); the scores are the plain forward's bit for bit. */
+int sgs_edge_score_fwd_mask(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
+                            int64_t edge_id_offset, const int32_t* canon, int64_t M, const int32_t* mate, const float* W1, const float* b1,
+                            const float* w2, const float* b2, float p_drop, uint64_t seed, uint32_t site, float* p_out, uint32_t* maskbits,
+                            void* ws, size_t ws_bytes, sgs_stream_t stream_) {
+    SGS_REQUIRE(maskbits || E == 0, SGS_EINVAL, "sgs_edge_score_fwd_mask: null pointer");
+    SGS_REQUIRE((canon != nullptr) == (mate != nullptr), SGS_EINVAL, "sgs_edge_score_fwd_mask: canon and mate come together");
+    return fwd_bf16x6_impl(codes, U, N, H, edge_index, E, edge_id_offset, canon, canon ? M : E, mate, W1, b1, w2, b2, p_drop, seed, site, p_out,
+                           maskbits, ws, ws_bytes, stream_);
+}
+
+static int fwd_bf16x6_impl(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
+                           int64_t edge_id_offset, const int32_t* canon, int64_t M, const int32_t* mate, const float* W1, const float* b1,
+                           const float* w2, const float* b2, float p_drop, uint64_t seed, uint32_t site, float* p_out, uint32_t* maskbits,
+                           void* ws, size_t ws_bytes, sgs_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (int rc = check_common("sgs_edge_score_fwd_paired", N, H, E, p_drop)) return rc;
     SGS_REQUIRE(sgs_edge_score_paired_supported(H), SGS_EINVAL, "sgs_edge_score_fwd_paired: H must be 128 or 256");
     SGS_REQUIRE(M >= 0 && M <= E, SGS_EINVAL, "sgs_edge_score_fwd_paired: bad canonical count");
     if (E == 0 || M == 0) return SGS_OK;
-    SGS_REQUIRE(codes && U && edge_index && canon && mate && W1 && b1 && w2 && b2 && p_out, SGS_EINVAL, "sgs_edge_score_fwd_paired: null pointer");
+    SGS_REQUIRE(codes && U && edge_index && W1 && b1 && w2 && b2 && p_out && N > 0, SGS_EINVAL, "sgs_edge_score_fwd_paired: null pointer");
     SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_workspace_bytes(N, H, E), SGS_EWORKSPACE, "sgs_edge_score_fwd_paired: workspace too small");
     Carver cv(ws);
     cv.take<float>(static_cast<size_t>(H) * H);
@@ -1556,14 +1678,20 @@ int sgs_edge_score_fwd_paired(const float* codes, const float* U, int64_t N, int
     a.row_offset = edge_id_offset;
     a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.drop_scale = 1.0f / (1.0f - p_drop); a.drop_thresh = dropout_thresh(p_drop); a.seed = seed; a.epoch = epoch_ptr(); a.site = site;
-    a.use_drop = p_drop > 0.f; a.p_out = p_out;
+    a.use_drop = p_drop > 0.f; a.p_out = p_out; a.dvbits = maskbits;
     a.canon = canon; a.mate = mate;
-    a.dyn_n = dyn_edges_ptr() ? dyn_edges_ptr() + 1 : nullptr;       // word 1 of the registered dims: the live number of canonical edges
     hipLaunchKernelGGL(pack_w1a_bf16x3<false>, dim3(static_cast<unsigned>(cdiv((H / 16) * (H / 32) * 64, kT))), dim3(kT), 0, stream, W1,
                        static_cast<int>(H), Wp16);
     const dim3 grid(static_cast<unsigned>(cdiv(M, 128))), blk(256);
-    if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4, 3>), grid, blk, 0, stream, a, Wp16);
-    else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4, 3>), grid, blk, 0, stream, a, Wp16);
+    if (canon) {
+        a.dyn_n = dyn_edges_ptr() ? dyn_edges_ptr() + 1 : nullptr;   // word 1 of the registered dims: the live number of canonical edges
+        if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4, 3>), grid, blk, 0, stream, a, Wp16);
+        else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4, 3>), grid, blk, 0, stream, a, Wp16);
+    } else {                                                         // every edge runs the contraction (no mates: a directed edge list)
+        a.dyn_n = dyn_edges_ptr();
+        if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4>), grid, blk, 0, stream, a, Wp16);
+        else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4>), grid, blk, 0, stream, a, Wp16);
+    }
     SGS_LAUNCH_OK();
     return SGS_OK;
 }
@@ -1785,10 +1913,35 @@ int sgs_endpoint_reduce_pair(const float* dfeat, const float* dv, const float* c
     return SGS_OK;
 }
 
+int sgs_edge_score_bwd_prep(const float* codes, int64_t N, int64_t H, const int64_t* edge_index, int64_t E, const int64_t* active_eid,
+                            int64_t n_active, const float* grad_p, const float* p, const uint32_t* maskbits, float* dz, uint32_t* dvbits,
+                            float* feat, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N > 0 && H > 0 && H % 32 == 0 && E >= 0 && n_active >= 0 && (active_eid || n_active == E), SGS_EINVAL,
+                "sgs_edge_score_bwd_prep: bad arguments (H %% 32 == 0; n_active == E when active_eid is NULL)");
+    if (n_active == 0) return SGS_OK;
+    SGS_REQUIRE(codes && edge_index && grad_p && p && maskbits && dz && dvbits && feat, SGS_EINVAL, "sgs_edge_score_bwd_prep: null pointer");
+    hipLaunchKernelGGL(scorer_bwd_prep, dim3(static_cast<unsigned>(cdiv(cdiv(n_active, 4) * 64, kT))), dim3(kT), 0, stream, codes, H, edge_index,
+                       edge_index + E, active_eid, n_active, grad_p, p, maskbits, dz, dvbits, feat);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_edge_score_dw2_from_parts(const float* W1, const float* T_raw, const float* U, const float* R_raw, const float* b1, const float* c_raw,
+                                  int64_t N, int64_t H, float p_drop, float* dw2, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N > 0 && H > 0 && p_drop >= 0.f && p_drop < 1.f && W1 && T_raw && U && R_raw && b1 && c_raw && dw2, SGS_EINVAL,
+                "sgs_edge_score_dw2_from_parts: bad arguments");
+    hipLaunchKernelGGL(scorer_dw2_from_parts, dim3(static_cast<unsigned>(H)), dim3(kT), 0, stream, W1, T_raw, U, R_raw, b1, c_raw, N,
+                       static_cast<int>(H), 1.0f / (1.0f - p_drop), dw2);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
 int sgs_endpoint_reduce_pair_bits(const float* dfeat, const uint32_t* dvbits, const float* dz, const float* w2, float p_drop, const float* codes,
                                   int64_t N, int64_t H, int64_t nnz, const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_eid,
                                   const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid, float* out_codes, float* out_U,
-                                  sgs_stream_t stream_) {
+                                  float* out_U_raw, sgs_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     SGS_REQUIRE(N >= 0 && H >= 0 && H % 32 == 0 && N < (int64_t(1) << 31) && p_drop >= 0.f && p_drop < 1.f, SGS_EINVAL,
                 "sgs_endpoint_reduce_pair_bits: needs H %% 32 == 0");
@@ -1800,10 +1953,10 @@ int sgs_endpoint_reduce_pair_bits(const float* dfeat, const uint32_t* dvbits, co
     const float* nodv = nullptr;
     if (nnz >= 64 * N)
         hipLaunchKernelGGL((endpoint_reduce_pair_rowblock<16, true>), grid, dim3(1024), 0, stream, dfeat, nodv, codes, N, H, in_ptr, in_src, in_eid,
-                           out_ptr, out_dst, out_eid, out_codes, out_U, dvbits, dz, w2, scale);
+                           out_ptr, out_dst, out_eid, out_codes, out_U, dvbits, dz, w2, scale, out_U_raw);
     else
         hipLaunchKernelGGL((endpoint_reduce_pair_rowblock<4, true>), grid, dim3(256), 0, stream, dfeat, nodv, codes, N, H, in_ptr, in_src, in_eid,
-                           out_ptr, out_dst, out_eid, out_codes, out_U, dvbits, dz, w2, scale);
+                           out_ptr, out_dst, out_eid, out_codes, out_U, dvbits, dz, w2, scale, out_U_raw);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

@@ -111,7 +111,8 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce(const float* __restrict__ 
                                                       const float* __restrict__ cpart = nullptr, int M = 0, float* __restrict__ colsum = nullptr,
                                                       int N = 0, int64_t ldc = 0, const float* __restrict__ rowscale = nullptr,
                                                       float scale = 1.f, const float* __restrict__ dzpart = nullptr, int nz = 0,
-                                                      float* __restrict__ dzsum = nullptr) {
+                                                      float* __restrict__ dzsum = nullptr, float* __restrict__ Craw = nullptr,
+                                                      float* __restrict__ csraw = nullptr) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (i >= mn) {
         const int64_t c = i - mn;                       // trailing threads: the column sums of A, slices in the same fixed order
@@ -123,12 +124,14 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce(const float* __restrict__ 
         if (colsum && c < M) {
             float acc = 0.f;
             for (int s = 0; s < ksplit; ++s) acc += cpart[static_cast<int64_t>(s) * M + c];
+            if (csraw) csraw[c] = acc;                  // (the sums before the row factor: a term of d fc2.weight)
             colsum[c] = rowscale ? acc * (rowscale[c] * scale) : acc;
         }
         return;
     }
     float acc = 0.f;
     for (int s = 0; s < ksplit; ++s) acc += slab[static_cast<int64_t>(s) * mn + i];
+    if (Craw) Craw[i] = acc;                             // dense [M, N], before the row factor
     if (rowscale) acc *= rowscale[i / N] * scale;        // mask-operand products: row m of C carries the factor left out of A
     if (ldc > 0 && ldc != N) C[(i / N) * ldc + (i % N)] = acc;
     else C[i] = acc;
@@ -493,7 +496,8 @@ size_t sgs_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N) {
 
 static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, float* colsum_A, void* ws,
                         size_t ws_bytes, hipStream_t stream, int64_t ldc = 0, const uint32_t* Abits = nullptr, const float* dz = nullptr,
-                        const float* rowscale = nullptr, float scale = 1.f, float* dz_sum = nullptr);
+                        const float* rowscale = nullptr, float scale = 1.f, float* dz_sum = nullptr, float* C_raw = nullptr,
+                        float* colsum_raw = nullptr);
 // tall-K shapes: 1 = bf16x6 kernel (default; measured 147 vs 175 us incl. the 34 us slab reduction at K = 100 000, M = N = 256: the
 // operand splits, 264 vector instructions per 48 MFMAs, are at the budget the matrix pipe leaves), 0 = fp32-MFMA kernel
 static int g_tall_bf16x6 = 1;
@@ -530,16 +534,19 @@ int sgs_gemm_tn_mask_supported(int64_t K, int64_t M, int64_t N) {
 }
 
 int sgs_gemm_tn_mask(const uint32_t* Abits, const float* dz, const float* rowscale, float scale, const float* B, int64_t K, int64_t M, int64_t N,
-                     float* C, int64_t ldc, float* colsum_A, float* dz_sum, void* ws, size_t ws_bytes, sgs_stream_t stream_) {
+                     float* C, int64_t ldc, float* colsum_A, float* dz_sum, float* C_raw, float* colsum_raw, void* ws, size_t ws_bytes,
+                     sgs_stream_t stream_) {
     SGS_REQUIRE(ldc >= N, SGS_EINVAL, "sgs_gemm_tn_mask: ldc < N");
     SGS_REQUIRE(Abits && dz && rowscale, SGS_EINVAL, "sgs_gemm_tn_mask: null pointer");
     SGS_REQUIRE(sgs_gemm_tn_mask_supported(K, M, N), SGS_EINVAL, "sgs_gemm_tn_mask: shape not served (check sgs_gemm_tn_mask_supported)");
-    return gemm_tn_impl(nullptr, B, K, M, N, C, colsum_A, ws, ws_bytes, static_cast<hipStream_t>(stream_), ldc, Abits, dz, rowscale, scale, dz_sum);
+    SGS_REQUIRE(!colsum_raw || colsum_A, SGS_EINVAL, "sgs_gemm_tn_mask: colsum_raw needs colsum_A");
+    return gemm_tn_impl(nullptr, B, K, M, N, C, colsum_A, ws, ws_bytes, static_cast<hipStream_t>(stream_), ldc, Abits, dz, rowscale, scale, dz_sum,
+                        C_raw, colsum_raw);
 }
 
 static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, float* colsum_A, void* ws,
                         size_t ws_bytes, hipStream_t stream, int64_t ldc, const uint32_t* Abits, const float* dz, const float* rowscale,
-                        float scale, float* dz_sum) {
+                        float scale, float* dz_sum, float* C_raw, float* colsum_raw) {
     SGS_REQUIRE(K >= 0 && M >= 0 && N >= 0 && M < (1 << 30) && N < (1 << 30), SGS_EINVAL, "sgs_gemm_tn: bad sizes");
     if (M == 0 || N == 0) return SGS_OK;
     SGS_REQUIRE(C && (K == 0 || ((A || Abits) && B)), SGS_EINVAL, "sgs_gemm_tn: null pointer");
@@ -568,7 +575,7 @@ static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, in
                            dzpart);
         hipLaunchKernelGGL(gemm_tn_reduce, dim3(cdiv(M * N + M + 1, 256)), dim3(256), 0, stream, slab, M * N, n_slabs, C,
                            static_cast<const float*>(colsum_A ? cpart : nullptr), static_cast<int>(M), colsum_A, static_cast<int>(N),
-                           ldc > 0 ? ldc : N, rowscale, scale, static_cast<const float*>(dzpart), ks, dz_sum);
+                           ldc > 0 ? ldc : N, rowscale, scale, static_cast<const float*>(dzpart), ks, dz_sum, C_raw, colsum_raw);
         SGS_LAUNCH_OK();
         return SGS_OK;
     }

@@ -567,6 +567,7 @@ def _endpoint_reduce(M_out, M_in, T, graph: Graph, s_out, s_in, H):
 
 
 _mask_backward = True        # False: the dense fp32 dv path at every size (tests compare the two)
+_fwd_mask = True             # False: the forward keeps no mask; the backward recomputes the hidden layer (sgs_edge_score_bwd_core_bits)
 
 
 class _EdgeScore(torch.autograd.Function):
@@ -582,7 +583,18 @@ class _EdgeScore(torch.autograd.Function):
         U = torch.mm(codes, W1[:, H:].t())
         out = torch.empty(E, dtype=torch.float32, device=codes.device)
         ws = workspace(L.sgs_edge_score_workspace_bytes(N, H, E), codes.device)
-        if pairs is not None and E >= 65536 and L.sgs_edge_score_paired_supported(H):
+        maskbits = None
+        if (_fwd_mask and _mask_backward and E >= 65536 and L.sgs_edge_score_bwd_bits_supported(H) and ctx.needs_input_grad[0]
+                and g_score_variant_default()):
+            # a forward whose backward will follow: keep the ReLU x dropout mask of every scored edge (one bit per hidden unit), so that the
+            # backward needs no recompute of the hidden layer (_edge_score_backward_mask)
+            maskbits = torch.empty(E, H // 32, dtype=torch.int32, device=codes.device)
+            canon, mate = pairs if pairs is not None else (None, None)
+            _lib.check(L.sgs_edge_score_fwd_mask(_ptr(codes, torch.float32), _ptr(U, torch.float32), N, H, _ptr(edge_index, torch.int64), E,
+                                                 edge_id_offset, _ptr(canon, torch.int32), 0 if canon is None else canon.numel(),
+                                                 _ptr(mate, torch.int32), _ptr(W1, torch.float32), _ptr(b1), _ptr(w2), _ptr(b2), float(p), seed, site,
+                                                 _ptr(out), _ptr(maskbits), ws.data_ptr(), ws.numel(), _stream()), "sgs_edge_score_fwd_mask")
+        elif pairs is not None and E >= 65536 and L.sgs_edge_score_paired_supported(H):
             # undirected graph stored both ways: the canonical half of the edges runs the contraction, every mate rides along
             canon, mate = pairs
             _lib.check(L.sgs_edge_score_fwd_paired(_ptr(codes, torch.float32), _ptr(U, torch.float32), N, H, _ptr(edge_index, torch.int64), E,
@@ -593,14 +605,15 @@ class _EdgeScore(torch.autograd.Function):
             _lib.check(L.sgs_edge_score_fwd(_ptr(codes, torch.float32), _ptr(U, torch.float32), N, H, _ptr(edge_index, torch.int64), E,
                                             edge_id_offset, _ptr(W1, torch.float32), _ptr(b1), _ptr(w2), _ptr(b2), float(p), seed, site, _ptr(out),
                                             ws.data_ptr(), ws.numel(), _stream()), "sgs_edge_score_fwd")
-        ctx.save_for_backward(codes, U, W1, b1, w2, b2, edge_index)
+        ctx.save_for_backward(codes, U, W1, b1, w2, b2, edge_index, *((maskbits, out) if maskbits is not None else ()))
         ctx.active, ctx.p, ctx.seed, ctx.site, ctx.offset = active, float(p), seed, site, edge_id_offset
         return out
 
     @staticmethod
     def backward(ctx, gp):
         L = _lib.lib()
-        codes, U, W1, b1, w2, b2, edge_index = ctx.saved_tensors
+        codes, U, W1, b1, w2, b2, edge_index = ctx.saved_tensors[:7]
+        kept = ctx.saved_tensors[7:]                  # (maskbits, p) when the forward kept the mask
         N, H = codes.shape
         E = edge_index.shape[1]
         dev = codes.device
@@ -622,7 +635,8 @@ class _EdgeScore(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         if (_mask_backward and n >= 65536 and L.sgs_edge_score_bwd_bits_supported(H) and L.sgs_gemm_tn_mask_supported(n, H, H)
                 and ctx.needs_input_grad[0]):
-            return _EdgeScore._backward_mask(ctx, L, codes, U, W1, b1, w2, b2, edge_index, eid, graph, n, gp_act)
+            return _EdgeScore._backward_mask(ctx, L, codes, U, W1, b1, w2, b2, edge_index, eid, graph, n, gp_act, kept)
+        # (a kept mask goes unused when the active set turns out too small for the mask-form kernels: the dense path recomputes)
         dv, feat = torch.empty(n, H, **f32), torch.empty(n, H, **f32)
         tile = L.sgs_edge_score_bwd_tile()
         hdz = torch.empty((n + tile - 1) // tile, H, **f32)          # per-tile column sums of dz * hidden (rows sum to d w2)
@@ -675,7 +689,15 @@ class _EdgeScore(torch.autograd.Function):
         return dcodes, dW1, db1, dw2, db2, None, None, None, None, None, None, None
 
 
-def _edge_score_backward_mask(ctx, L, codes, U, W1, b1, w2, b2, edge_index, eid, graph, n, gp_act):
+def g_score_variant_default() -> bool:
+    """True while the library's forward / backward variant overrides are at their defaults (sgs_edge_score_set_variant(-1),
+    sgs_edge_score_set_bwd_variant(-1)): only then may the mask-keeping forward (always the bf16x6 loop) stand in for the kernels a test or
+    the bench asked for by name."""
+    L = _lib.lib()
+    return L.sgs_edge_score_get_variant() < 0 and L.sgs_edge_score_get_bwd_variant() < 0
+
+
+def _edge_score_backward_mask(ctx, L, codes, U, W1, b1, w2, b2, edge_index, eid, graph, n, gp_act, kept=()):
     """The backward at production size in its MASK form (include/sgs_hip.h, sgs_edge_score_bwd_core_bits): dv = dz x [hidden > 0] x w2 / (1 - p)
     never exists as an fp32 [n, H] matrix -- the core writes one bit per entry and the three consumers rebuild what they need, the two
     contractions with a 0 / 1 operand at half the MFMA work."""
@@ -686,13 +708,21 @@ def _edge_score_backward_mask(ctx, L, codes, U, W1, b1, w2, b2, edge_index, eid,
     p = ctx.p
     bits = torch.empty(n, H // 32, dtype=torch.int32, device=dev)
     feat = torch.empty(n, H, **f32)
-    tile = L.sgs_edge_score_bwd_tile()
-    hdz = torch.empty((n + tile - 1) // tile, H, **f32)
     dz = torch.empty(n, **f32)
-    ws = workspace(L.sgs_edge_score_workspace_bytes(N, H, 0), dev)
-    _lib.check(L.sgs_edge_score_bwd_core_bits(_ptr(codes), _ptr(U), N, H, _ptr(edge_index), E, ctx.offset, _ptr(eid), n, _ptr(gp_act), _ptr(W1),
-                                              _ptr(b1), _ptr(w2), _ptr(b2), p, ctx.seed, ctx.site, _ptr(bits), _ptr(hdz), _ptr(dz), _ptr(feat),
-                                              ws.data_ptr(), ws.numel(), _stream()), "sgs_edge_score_bwd_core_bits")
+    hdz = Traw = craw = Rraw = None
+    if kept:
+        # the forward kept the mask and p: no recompute -- dz, the active rows' mask and feat in one pass; d fc2.weight from the consumers' parts
+        maskbits, p_out = kept
+        _lib.check(L.sgs_edge_score_bwd_prep(_ptr(codes), N, H, _ptr(edge_index), E, _ptr(eid), n, _ptr(gp_act), _ptr(p_out), _ptr(maskbits),
+                                             _ptr(dz), _ptr(bits), _ptr(feat), _stream()), "sgs_edge_score_bwd_prep")
+        Traw, craw, Rraw = torch.empty(H, H, **f32), torch.empty(H, **f32), torch.empty(N, H, **f32)
+    else:
+        tile = L.sgs_edge_score_bwd_tile()
+        hdz = torch.empty((n + tile - 1) // tile, H, **f32)
+        ws = workspace(L.sgs_edge_score_workspace_bytes(N, H, 0), dev)
+        _lib.check(L.sgs_edge_score_bwd_core_bits(_ptr(codes), _ptr(U), N, H, _ptr(edge_index), E, ctx.offset, _ptr(eid), n, _ptr(gp_act), _ptr(W1),
+                                                  _ptr(b1), _ptr(w2), _ptr(b2), p, ctx.seed, ctx.site, _ptr(bits), _ptr(hdz), _ptr(dz), _ptr(feat),
+                                                  ws.data_ptr(), ws.numel(), _stream()), "sgs_edge_score_bwd_core_bits")
     dfeat = torch.empty(n, H, **f32)
     wsd = workspace(L.sgs_edge_score_workspace_bytes(0, H, 0), dev)
     _lib.check(L.sgs_edge_score_bwd_dfeat_bits(_ptr(bits), _ptr(dz), n, H, _ptr(W1), _ptr(w2), p, _ptr(dfeat), wsd.data_ptr(), wsd.numel(),
@@ -702,14 +732,18 @@ def _edge_score_backward_mask(ctx, L, codes, U, W1, b1, w2, b2, edge_index, eid,
     scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))        # as the kernels form it: 1.0f / (1.0f - p)
     wsg = workspace(L.sgs_gemm_tn_workspace_bytes(n, H, H), dev)
     db2 = torch.empty(1, **f32)
-    _lib.check(L.sgs_gemm_tn_mask(_ptr(bits), _ptr(dz), _ptr(w2), scale, _ptr(feat), n, H, H, _ptr(dW1), 2 * H, _ptr(db1), _ptr(db2), wsg.data_ptr(),
-                                  wsg.numel(), _stream()), "sgs_gemm_tn_mask")
-    dw2 = _colsum(hdz)
+    _lib.check(L.sgs_gemm_tn_mask(_ptr(bits), _ptr(dz), _ptr(w2), scale, _ptr(feat), n, H, H, _ptr(dW1), 2 * H, _ptr(db1), _ptr(db2), _ptr(Traw),
+                                  _ptr(craw), wsg.data_ptr(), wsg.numel(), _stream()), "sgs_gemm_tn_mask")
+    dw2 = _colsum(hdz) if hdz is not None else None
     dcodes = torch.empty(N, H, **f32)
     dU = torch.empty(N, H, **f32)
     _lib.check(L.sgs_endpoint_reduce_pair_bits(_ptr(dfeat), _ptr(bits), _ptr(dz), _ptr(w2), p, _ptr(codes), N, H, graph.n_edges, _ptr(graph.in_ptr),
                                                _ptr(graph.in_src), _ptr(graph.in_eid), _ptr(graph.out_ptr), _ptr(graph.out_dst),
-                                               _ptr(graph.out_eid), _ptr(dcodes), _ptr(dU), _stream()), "sgs_endpoint_reduce_pair_bits")
+                                               _ptr(graph.out_eid), _ptr(dcodes), _ptr(dU), _ptr(Rraw), _stream()), "sgs_endpoint_reduce_pair_bits")
+    if dw2 is None:
+        dw2 = torch.empty(H, **f32)
+        _lib.check(L.sgs_edge_score_dw2_from_parts(_ptr(W1), _ptr(Traw), _ptr(U), _ptr(Rraw), _ptr(b1), _ptr(craw), N, H, p, _ptr(dw2), _stream()),
+                   "sgs_edge_score_dw2_from_parts")
     return _edge_score_backward_mask_tail(L, codes, W1, dcodes, dU, dW1, db1, dw2, db2)
 
 

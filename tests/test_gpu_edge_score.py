@@ -124,30 +124,34 @@ def test_production_size_forward_and_active_backward_vs_fp64_oracle(ops, p):
 
 @pytest.mark.parametrize("N,H,p", [(777, 256, 0.3), (777, 128, 0.0), (777, 256, 0.0), (70_001, 128, 0.3)])
 def test_mask_backward_equals_dense_backward(ops, N, H, p):
-    """The mask form of the backward (one bit per entry of dv; 0 / 1 operands in the two contractions, 3 bf16 products instead of 6)
-    against the dense fp32-dv path on the same inputs: the same five gradients to fp32 rounding (they differ only in where the row and
-    column factors dz, w2 / (1 - p) are multiplied in)."""
-    E, q = 140_000, 66_000                     # (N > 65 536: the wave-per-node reductions of whole graphs, d U from the mask bits)
+    """Three forms of the backward on the same inputs: (a) the forward keeps the ReLU x dropout mask and the backward recomputes nothing
+    (dz from p, d fc2.weight from the consumers' parts), (b) the core recomputes the hidden layer and writes dv as one bit per entry,
+    (c) the dense fp32-dv path.  The same five gradients to fp32 rounding: (a) and (b) differ from (c) only in where the row and column
+    factors dz, w2 / (1 - p) are multiplied in, (a) from (b) in how d fc2.weight is summed."""
+    E, q = 140_000, 66_000                     # (N > 65 536: the row-block reductions on a whole graph)
     codes, ei, W1, b1, W2, b2, g = _case(N, H, E, 99)
     eid = torch.sort(torch.randperm(E, generator=g)[:q]).values
     gp = torch.zeros(E)
     gp[eid] = torch.randn(q, generator=g)
     sub = ei[:, eid]
-    grads = {}
-    for mask in (True, False):
-        ops._mask_backward = mask
+    grads, probs = {}, {}
+    for form, (fwd_mask, mask) in {"kept": (True, True), "bits": (False, True), "dense": (False, False)}.items():
+        ops._fwd_mask, ops._mask_backward = fwd_mask, mask
         try:
             dl = [t.clone().to(DEV).requires_grad_(True) for t in (codes, W1, b1, W2, b2)]
             act = ops.ActiveSet()
             pd = ops.edge_score(dl[0], dl[1], dl[2], dl[3], dl[4], ei.to(DEV), active=act, p=p, seed=5, site=2)
             act.set(eid.to(DEV), ops.Graph(sub.to(DEV), N))
             pd.backward(gp.to(DEV))
-            grads[mask] = [t.grad.detach().cpu() for t in dl]
+            grads[form] = [t.grad.detach().cpu() for t in dl]
+            probs[form] = pd.detach().cpu()
         finally:
-            ops._mask_backward = True
-    for name, a, b in zip(["dcodes", "dW1", "db1", "dW2", "db2"], grads[True], grads[False]):
-        assert bool(torch.isfinite(a).all()), name
-        assert _rel(a, b) < 3e-6, (name, _rel(a, b))
+            ops._fwd_mask, ops._mask_backward = True, True
+    assert torch.equal(probs["kept"], probs["dense"])                      # the mask-keeping forward scores bit for bit as the plain one
+    for form in ("kept", "bits"):
+        for name, a, b in zip(["dcodes", "dW1", "db1", "dW2", "db2"], grads[form], grads["dense"]):
+            assert bool(torch.isfinite(a).all()), (form, name)
+            assert _rel(a, b) < 3e-6, (form, name, _rel(a, b))
 
 
 @pytest.mark.parametrize("H,p", [(256, 0.3), (128, 0.0)])
