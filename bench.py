@@ -129,11 +129,16 @@ def kernel_roofline(S, model, batch, reps, n_nodes=N_NODES, hid=HID, paired=Fals
         canon, mate = ops.get_pairs(batch.edge_index, n_nodes, build=True)
         M = int(canon.numel())
 
+    maskbits = torch.empty(E, H // 32, dtype=torch.int32, device=codes.device) if paired else None
+
     def launch():
         if paired:
-            S._lib.check(L.sgs_edge_score_fwd_paired(codes.data_ptr(), U.data_ptr(), n_nodes, H, batch.edge_index.data_ptr(), E, 0, canon.data_ptr(), M,
-                                                     mate.data_ptr(), W1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), 0.3, 1, 2, out.data_ptr(),
-                                                     ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), "edge_score_fwd_paired")
+            # what a TRAINING step's forward runs (ops._EdgeScore.forward with gradients enabled): the paired loop that also keeps the
+            # ReLU x dropout mask of every scored edge for the backward
+            S._lib.check(L.sgs_edge_score_fwd_mask(codes.data_ptr(), U.data_ptr(), n_nodes, H, batch.edge_index.data_ptr(), E, 0, canon.data_ptr(), M,
+                                                   mate.data_ptr(), W1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), 0.3, 1, 2, out.data_ptr(),
+                                                   maskbits.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+                         "edge_score_fwd_mask")
         else:
             S._lib.check(L.sgs_edge_score_fwd(codes.data_ptr(), U.data_ptr(), n_nodes, H, batch.edge_index.data_ptr(), E, 0, W1.data_ptr(),
                                               b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), 0.3, 1, 2, out.data_ptr(), ws.data_ptr(),
@@ -168,7 +173,8 @@ def scorer_roofline(S, model, big, score_variant, n_nodes=N_NODES, hid=HID, alts
     roof = kernel_roofline(S, model, big, reps=20, n_nodes=n_nodes, hid=hid, paired=paired)       # the entry point the timed steps use
     if paired:
         used = 5
-        roof["kernel"] = "sgs_edge_score_fwd_paired (bf16x6 loop, MODE 3: canonical edges run the contraction, mates ride along)"
+        roof["kernel"] = ("sgs_edge_score_fwd_mask (the training forward: paired bf16x6 loop, MODE 3 -- canonical edges run the contraction, mates "
+                          "ride along -- that also keeps the ReLU x dropout mask of every scored edge for the backward)")
         roof["peak"] = round(BF16X6_PEAK_TFLOPS, 1)
         roof["frac"] = round(roof["achieved"] / BF16X6_PEAK_TFLOPS, 4)
         roof["peak_note"] = ("achieved = ALGORITHMIC fp32 flops (2 H^2 + 2 H per CANDIDATE edge, SURVEY.md 8d) / time; peak = dense bf16 MFMA peak 2500 / 6 "

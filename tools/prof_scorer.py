@@ -23,8 +23,14 @@ if len(sys.argv) > 3 and sys.argv[3] == "paired":
     ei = S.reddit_partition_stream(num_parts=230, seed=1000, nfeat=602, ncls=41, n=N, q=100_000, device=dev, only={idx})[idx].edge_index
     pairs = S.ops.get_pairs(ei, N, build=True)
     print("paired: E", ei.shape[1], "canonical", pairs[0].numel())
-with torch.no_grad():
+if pairs is not None:
+    # the TRAINING forward (gradients enabled): the paired loop that also keeps the mask of every scored edge (sgs_edge_score_fwd_mask)
+    codes.requires_grad_(True)
     for _ in range(reps):
-        p = S.ops.edge_score(codes, fc1.weight, fc1.bias, fc2.weight, fc2.bias, ei, p=0.3, seed=1, site=2, pairs=pairs)
+        p = S.ops.edge_score(codes, fc1.weight, fc1.bias, fc2.weight, fc2.bias, ei, p=0.3, seed=1, site=2, pairs=pairs).detach()
+else:
+    with torch.no_grad():
+        for _ in range(reps):
+            p = S.ops.edge_score(codes, fc1.weight, fc1.bias, fc2.weight, fc2.bias, ei, p=0.3, seed=1, site=2, pairs=pairs)
 torch.cuda.synchronize()
 print("ok", float(p.mean()))
