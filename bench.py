@@ -333,9 +333,10 @@ def run_s3(a, S, rank, world, device):
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt_all / a.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "dtype_note": "fp32 tensors, accumulators and results throughout; the scorer's fp32 contractions (forward, and the backward's "
-                      "recompute) run as six bf16 MFMA products over exact 3-way operand splits (error measured at the fp32-MFMA kernels' "
+                      "recompute where one is needed) run as six bf16 MFMA products over exact 3-way operand splits (error measured at the fp32-MFMA kernels' "
                       "level, see roofline.peak_note); the backward's dv.W1a and weight-gradient GEMM take dv as its exact 0/1 mask "
-                      "(ReLU x dropout) times row / column factors, so one operand is a single exact bf16 piece: three products",
+                      "(ReLU x dropout, kept by the training forward) times row / column factors, so one operand is a single exact bf16 piece: "
+                      "three products; no recompute of the hidden layer in the backward",
         "data": "synthetic",
         "config": {"workload": f"Reddit-like METIS partition stream (S3): {P} partitions per GPU, shuffled, n=1013 F=602 C=41 H=256, E_b in "
                                "[60k,500k] (52% above q), q=100000, hybrid pipeline, EdgeProbGCN scorer, conditional gate, reg1+reg2, "

@@ -32,7 +32,7 @@ wave_cyc = sq["SQ_WAVE_CYCLES"]
 fetch_kb, write_kb = fe["FETCH_SIZE"], wr["WRITE_SIZE"]
 hit, miss = wr.get("TCC_HIT_sum", 0.0), wr.get("TCC_MISS_sum", 0.0)
 rec = {
-    "kernel": f"{needle} ({'sgs_edge_score_fwd_paired' if ', 3>' in needle else 'sgs_edge_score_fwd'}), E={E}, N={N}, H={H}, dropout 0.3",
+    "kernel": f"{needle} ({'sgs_edge_score_fwd_mask: the training forward, paired + mask of every scored edge kept' if ', 3>' in needle else 'sgs_edge_score_fwd'}), E={E}, N={N}, H={H}, dropout 0.3",
     "command": f"rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 tools/prof_scorer.py {E} 6  (three separate passes)",
     "dispatches_averaged": n,
     "avg_duration_us_under_pmc": round(dur, 1),
