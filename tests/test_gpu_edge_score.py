@@ -155,6 +155,73 @@ def test_mask_backward_equals_dense_backward(ops, N, H, p):
 
 
 @pytest.mark.parametrize("H,p", [(256, 0.3), (128, 0.0)])
+def test_forward_mask_prep_and_dw2_parts_entry_points(ops, H, p):
+    """The entry points of the no-recompute backward, one by one, through the C ABI:
+    sgs_edge_score_fwd_mask -- scores bit-identical to sgs_edge_score_fwd, mask bits == [dropout(relu(v)) > 0] from the fp64 oracle's
+    pre-activations (entries with |v| < 1e-5 excepted: the sign of a rounding-level v may differ);
+    sgs_edge_score_bwd_prep -- dz = gp p (1 - p), the active rows' mask, feat = x_s * x_d, exactly;
+    sgs_edge_score_dw2_from_parts -- against sum_e dz_e hidden[e, :] in fp64 from parts built in fp64."""
+    import sgs_gnn_amd as S
+    L = S._lib.lib()
+    N, E, q = 500, 70_000, 66_000
+    codes, ei, W1, b1, W2, b2, g = _case(N, H, E, 31)
+    seed, site = 11, 2
+    d = lambda t: t.to(DEV).contiguous()
+    codes_d, ei_d, W1_d, b1_d, w2_d, b2_d = d(codes), d(ei), d(W1), d(b1), d(W2.reshape(-1)), d(b2)
+    U_d = (codes_d @ W1_d[:, H:].t()).contiguous()
+    ws = ops.workspace(L.sgs_edge_score_workspace_bytes(N, H, E), codes_d.device)
+    p_plain = torch.empty(E, device=DEV)
+    p_mask = torch.empty(E, device=DEV)
+    bits = torch.zeros(E, H // 32, dtype=torch.int32, device=DEV)
+    st = ops._stream()
+    S._lib.check(L.sgs_edge_score_fwd(codes_d.data_ptr(), U_d.data_ptr(), N, H, ei_d.data_ptr(), E, 0, W1_d.data_ptr(), b1_d.data_ptr(), w2_d.data_ptr(),
+                                      b2_d.data_ptr(), p, seed, site, p_plain.data_ptr(), ws.data_ptr(), ws.numel(), st), "fwd")
+    S._lib.check(L.sgs_edge_score_fwd_mask(codes_d.data_ptr(), U_d.data_ptr(), N, H, ei_d.data_ptr(), E, 0, None, 0, None, W1_d.data_ptr(), b1_d.data_ptr(),
+                                           w2_d.data_ptr(), b2_d.data_ptr(), p, seed, site, p_mask.data_ptr(), bits.data_ptr(), ws.data_ptr(), ws.numel(), st),
+                 "fwd_mask")
+    assert torch.equal(p_plain, p_mask)
+    # mask bits vs the oracle's pre-activations
+    keep = ops.dropout_keep(seed, site, E, H, p, DEV).cpu() if p > 0 else torch.ones(E, H, dtype=torch.bool)
+    x, y = codes.double()[ei[0]], codes.double()[ei[1]]
+    v = torch.cat([x * y, x - y], 1) @ W1.double().t() + b1.double()
+    want = (v > 0) & keep
+    got = ((bits.cpu().view(E, H // 32, 1) >> torch.arange(32).view(1, 1, 32)) & 1).bool().view(E, H)
+    clear = v.abs() > 1e-5
+    assert bool((got == want)[clear].all()) and float(clear.double().mean()) > 0.999
+    # prep
+    eid = torch.sort(torch.randperm(E, generator=g)[:q]).values
+    gq = torch.randn(q, generator=g)
+    dz = torch.empty(q, device=DEV)
+    bact = torch.empty(q, H // 32, dtype=torch.int32, device=DEV)
+    feat = torch.empty(q, H, device=DEV)
+    eid_d, gq_d = d(eid), d(gq)                  # (held in variables: a temporary's storage may be handed to the next allocation)
+    S._lib.check(L.sgs_edge_score_bwd_prep(codes_d.data_ptr(), N, H, ei_d.data_ptr(), E, eid_d.data_ptr(), q, gq_d.data_ptr(), p_mask.data_ptr(),
+                                           bits.data_ptr(), dz.data_ptr(), bact.data_ptr(), feat.data_ptr(), st), "prep")
+    torch.cuda.synchronize()
+    pc = p_mask.cpu()[eid]
+    assert torch.equal(dz.cpu(), gq * pc * (1.0 - pc))
+    assert torch.equal(bact.cpu(), bits.cpu()[eid])
+    assert torch.equal(feat.cpu(), codes[ei[0, eid]] * codes[ei[1, eid]])
+    # d fc2.weight from parts (built here in fp64 from the kernel's own mask)
+    scale = 1.0 / (1.0 - p)
+    m = got[eid].double()
+    dzd = dz.cpu().double()
+    T = (m * dzd[:, None]).t() @ (codes.double()[ei[0, eid]] * codes.double()[ei[1, eid]])
+    c = (m * dzd[:, None]).sum(0)
+    R = torch.zeros(N, H, dtype=torch.float64)
+    R.index_add_(0, ei[0, eid], m * dzd[:, None])
+    R.index_add_(0, ei[1, eid], -(m * dzd[:, None]))
+    dw2 = torch.empty(H, device=DEV)
+    T_d, R_d, c_d = d(T.float()), d(R.float()), d(c.float())
+    S._lib.check(L.sgs_edge_score_dw2_from_parts(W1_d.data_ptr(), T_d.data_ptr(), U_d.data_ptr(), R_d.data_ptr(), b1_d.data_ptr(), c_d.data_ptr(), N, H,
+                                                 p, dw2.data_ptr(), st), "dw2")
+    torch.cuda.synchronize()
+    hidden = torch.where(got[eid], v[eid] * scale, torch.zeros((), dtype=torch.float64))
+    ref = (dzd[:, None] * hidden).sum(0)
+    assert _rel(dw2, ref) < 2e-5, _rel(dw2, ref)
+
+
+@pytest.mark.parametrize("H,p", [(256, 0.3), (128, 0.0)])
 def test_paired_forward_equals_plain_forward_bitwise(ops, H, p):
     """sgs_edge_score_fwd_paired (only the canonical edge of every (s -> d), (d -> s) pair runs the H x H contraction; both scores
     are finished from one set of accumulators) against sgs_edge_score_fwd on the same inputs: bit-identical p for every edge, on
