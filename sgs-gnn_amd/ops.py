@@ -585,7 +585,7 @@ class _EdgeScore(torch.autograd.Function):
         ws = workspace(L.sgs_edge_score_workspace_bytes(N, H, E), codes.device)
         maskbits = None
         if (_fwd_mask and _mask_backward and E >= 65536 and L.sgs_edge_score_bwd_bits_supported(H) and ctx.needs_input_grad[0]
-                and g_score_variant_default()):
+                and _variant_overrides_are_default()):
             # a forward whose backward will follow: keep the ReLU x dropout mask of every scored edge (one bit per hidden unit), so that the
             # backward needs no recompute of the hidden layer (_edge_score_backward_mask)
             maskbits = torch.empty(E, H // 32, dtype=torch.int32, device=codes.device)
@@ -689,7 +689,7 @@ class _EdgeScore(torch.autograd.Function):
         return dcodes, dW1, db1, dw2, db2, None, None, None, None, None, None, None
 
 
-def g_score_variant_default() -> bool:
+def _variant_overrides_are_default() -> bool:
     """True while the library's forward / backward variant overrides are at their defaults (sgs_edge_score_set_variant(-1),
     sgs_edge_score_set_bwd_variant(-1)): only then may the mask-keeping forward (always the bf16x6 loop) stand in for the kernels a test or
     the bench asked for by name."""
