@@ -427,6 +427,15 @@ int sgs_masked_correct(const float* logits, int64_t N, int64_t C, const int64_t*
  * correct4 = {#correct_a, #train, #correct_b, #train}; correct4 must be ZERO on entry (it is accumulated into). */
 int sgs_masked_correct_pair(const float* logits_a, const float* logits_b, int64_t N, int64_t C, const int64_t* y,
                             const uint8_t* train_mask, int32_t* correct4, sgs_stream_t stream);
+
+/* The gate of training_hybrid.py:95-103 in two launches, no zero fill, no atomics: out5[0..3] = (#correct_a, #train, #correct_b, #train)
+ * (argmax of each logit matrix against y on the train rows; lowest index on ties), out5[4] = 0.  With dst_host_mapped (pinned,
+ * device-mapped host int32[5]) the finishing launch also hands the four counts to the host as sgs_publish_to_host does (payload, then
+ * seq_dev[0] -- or 1 -- as the sequence word with release semantics).  ws: sgs_gate_counts_workspace_bytes(N). */
+size_t sgs_gate_counts_workspace_bytes(int64_t N);
+int sgs_gate_counts(const float* logits_a, const float* logits_b, int64_t N, int64_t C, const int64_t* y, const uint8_t* train_mask,
+                    int32_t* out5, const uint64_t* seq_dev, int32_t* dst_host_mapped, void* ws, size_t ws_bytes, sgs_stream_t stream);
+
 /* Closing launch of a replayed step: loss_sum[0] += loss[0] and epoch[0] += 1 (either pair may be NULL). */
 int sgs_loss_tick(float* loss_sum, const float* loss, uint64_t* epoch, sgs_stream_t stream);
 /* Publish n (<= 63) device words to pinned, device-mapped HOST memory: dst[0..n) = src[0..n), then dst[n] = low 32 bits

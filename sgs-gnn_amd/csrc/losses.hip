@@ -76,6 +76,62 @@ __global__ void __launch_bounds__(1024) masked_correct_pair(const float* __restr
     }
 }
 
+// The gate in two launches with no zero fill and no atomics: gate_counts_partial = masked_correct_pair's row scan, but every workgroup
+// writes its own (#correct, #rows) pair; gate_counts_finish (one wave) adds them in order, writes out[0..3] = (#correct_a, #train,
+// #correct_b, #train), out[4] = 0 and -- with `dst` -- hands the four counts to the polling host exactly as publish_words does.
+__global__ void __launch_bounds__(1024) gate_counts_partial(const float* __restrict__ logits_a, const float* __restrict__ logits_b, int64_t N,
+                                                           int64_t C, const int64_t* __restrict__ y, const uint8_t* __restrict__ mask,
+                                                           int2* __restrict__ part) {
+    __shared__ int red[2 * 16];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 16 + wid;
+    const float* __restrict__ logits = blockIdx.y ? logits_b : logits_a;
+    int ok = 0, row = 0;
+    if (i < N && mask[i]) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int64_t c = lane; c < C; c += 64) {
+            const float v = logits[i * C + c];
+            if (v > best || (v == best && static_cast<int>(c) < bi) || bi == 0x7fffffff) { best = v; bi = static_cast<int>(c); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+        }
+        row = 1;
+        ok = (static_cast<int64_t>(bi) == y[i]) ? 1 : 0;
+    }
+    if (lane == 0) { red[2 * wid] = ok; red[2 * wid + 1] = row; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a_ = 0, b_ = 0;
+        for (int w = 0; w < 16; ++w) { a_ += red[2 * w]; b_ += red[2 * w + 1]; }
+        part[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = make_int2(a_, b_);
+    }
+}
+__global__ void __launch_bounds__(64) gate_counts_finish(const int2* __restrict__ part, int nblk, int* __restrict__ out,
+                                                        const uint64_t* __restrict__ seq, int32_t* __restrict__ dst) {
+    int a0 = 0, r0 = 0, a1 = 0, r1 = 0;
+    for (int b = threadIdx.x; b < nblk; b += 64) {
+        const int2 pa = part[b], pb = part[nblk + b];
+        a0 += pa.x; r0 += pa.y; a1 += pb.x; r1 += pb.y;
+    }
+    a0 = wave_sum_int_all(a0); r0 = wave_sum_int_all(r0); a1 = wave_sum_int_all(a1); r1 = wave_sum_int_all(r1);
+    if (threadIdx.x == 0) {
+        out[0] = a0; out[1] = r0; out[2] = a1; out[3] = r1; out[4] = 0;
+        if (dst) {
+            __hip_atomic_store(dst + 0, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(dst + 1, r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(dst + 2, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(dst + 3, r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            __hip_atomic_store(dst + 4, static_cast<int32_t>(seq ? seq[0] : 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // End of a replayed step in one launch: running loss += this step's loss, RNG epoch += 1 (the next replay draws fresh noise).
 __global__ void loss_tick(float* __restrict__ sum, const float* __restrict__ loss, uint64_t* __restrict__ epoch) {
     if (threadIdx.x == 0) {
@@ -366,6 +422,25 @@ int sgs_masked_correct_pair(const float* logits_a, const float* logits_b, int64_
     SGS_REQUIRE(logits_a && logits_b && y && train_mask, SGS_EINVAL, "sgs_masked_correct_pair: null pointer");
     hipLaunchKernelGGL(masked_correct_pair, dim3(static_cast<unsigned>(cdiv(N, 16)), 2), dim3(1024), 0, stream, logits_a, logits_b, N, C, y, train_mask,
                        correct4);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+size_t sgs_gate_counts_workspace_bytes(int64_t N) { return carve_bytes(static_cast<size_t>(2 * (cdiv(N < 0 ? 0 : N, 16) + 1)), 8) + 256; }
+
+int sgs_gate_counts(const float* logits_a, const float* logits_b, int64_t N, int64_t C, const int64_t* y, const uint8_t* train_mask,
+                    int32_t* out5, const uint64_t* seq_dev, int32_t* dst_host_mapped, void* ws, size_t ws_bytes, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && N < (int64_t(1) << 30) && C > 0 && out5, SGS_EINVAL, "sgs_gate_counts: bad arguments");
+    SGS_REQUIRE(N == 0 || (logits_a && logits_b && y && train_mask), SGS_EINVAL, "sgs_gate_counts: null pointer");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_gate_counts_workspace_bytes(N), SGS_EWORKSPACE, "sgs_gate_counts: workspace too small");
+    Carver cv(ws);
+    const int nblk = static_cast<int>(cdiv(N, 16));
+    int2* part = reinterpret_cast<int2*>(cv.take<int64_t>(static_cast<size_t>(2 * (nblk + 1))));
+    if (nblk > 0)
+        hipLaunchKernelGGL(gate_counts_partial, dim3(static_cast<unsigned>(nblk), 2), dim3(1024), 0, stream, logits_a, logits_b, N, C, y, train_mask,
+                           part);
+    hipLaunchKernelGGL(gate_counts_finish, dim3(1), dim3(64), 0, stream, static_cast<const int2*>(part), nblk, out5, seq_dev, dst_host_mapped);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

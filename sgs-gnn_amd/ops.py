@@ -806,6 +806,28 @@ def masked_correct_pair(logits_a, logits_b, y, train_mask, out) -> torch.Tensor:
     return out
 
 
+def gate_counts(logits_a, logits_b, y, train_mask, publish=None) -> torch.Tensor:
+    """The gate's counts: int32[5] on the device = (#correct_a, #train, #correct_b, #train, 0), two launches, no zero fill.
+    `publish` = (seq, dst_pinned): the finishing launch also hands the four counts to the host (as publish_to_host)."""
+    L = _lib.lib()
+    _need_gpu(logits_a, logits_b, y, train_mask)
+    N, C = logits_a.shape
+    if logits_b.shape != logits_a.shape:
+        raise RuntimeError("gate_counts: logits shapes differ")
+    out = torch.empty(5, dtype=torch.int32, device=logits_a.device)
+    seq_p = dst_p = None
+    if publish is not None:
+        seq, dst = publish
+        if dst.is_cuda or not dst.is_pinned() or dst.dtype != torch.int32 or dst.numel() < 5:
+            raise RuntimeError("gate_counts: the publish destination must be a pinned host int32 tensor with 5 entries")
+        seq_p, dst_p = (None if seq is None else seq.data_ptr()), dst.data_ptr()
+    ws = workspace(L.sgs_gate_counts_workspace_bytes(N), logits_a.device)
+    _lib.check(L.sgs_gate_counts(_ptr(logits_a.contiguous(), torch.float32), _ptr(logits_b.contiguous(), torch.float32), N, C, _ptr(y, torch.int64),
+                                 _ptr(_u8(train_mask)), _ptr(out, torch.int32), seq_p, dst_p, ws.data_ptr(), ws.numel(), _stream()),
+               "sgs_gate_counts")
+    return out
+
+
 def loss_tick(loss_sum, loss, epoch) -> None:
     """sgs_loss_tick: loss_sum += loss and epoch += 1 in one launch (the last kernel of a replayed step)."""
     L = _lib.lib()

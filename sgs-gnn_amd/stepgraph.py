@@ -550,9 +550,7 @@ class StepGraphs:
         with torch.cuda.graph(c.g1, stream=self.stream, pool=pool, capture_error_mode=self.capture_mode):
             st = sampled_forward(self.pipeline, a, self.model, batch, self.q, self.use_checkpoint,
                                  side_stream=self.side if _DEBUG == "fork" else None,   # measured: a forked capture is SLOWER here
-                                 prefix=pre)
-            if st.cbuf is not None:
-                ops.publish_to_host(st.cbuf, 4, self.epoch_word, self.host_gate)
+                                 prefix=pre, gate_publish=(self.epoch_word, self.host_gate))
         pool = c.g1.pool()
         c.cbuf = st.cbuf
         if self.debug_keep:

@@ -67,14 +67,16 @@ def sampled_prefix(args, batch, q, noise=None):
     return rs
 
 
-def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise=None, side_stream=None, prefix=None) -> SampledForward:
+def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise=None, side_stream=None, prefix=None,
+                    gate_publish=None) -> SampledForward:
     """training_hybrid.py:44-101 (ST 41-90, TP 41-92) up to the gate's inputs: prior draw, pass-1 scores, learned
     draw, encoder over the learned graph, encoder over the random graph, the two correct-counts (device side).
     No host read-back in here, so the whole segment can be captured into a HIP graph (stepgraph.py).
     `side_stream` (graph capture only): the encoder over the random graph depends on the prior draw alone, so it is issued
     on a second stream right after that draw and joins before the learned encoder -- in the captured graph it becomes a
     parallel branch beside the scorer instead of ~4 more dependent launches on the critical path.  (Kept as an option:
-    measured slower on ROCm 7.2, see stepgraph.py.)"""
+    measured slower on ROCm 7.2, see stepgraph.py.)  `gate_publish` = (sequence word, pinned host int32[5]): the launch that finishes
+    the gate counts also writes them to the host."""
     noise = noise or {}
     st = SampledForward()
     N = batch.x.shape[0]
@@ -127,8 +129,8 @@ def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise
     if args.conditional:
         if st.random_out is None:
             st.random_out = model(batch, st.rsei)
-        st.cbuf = torch.zeros(5, dtype=torch.int32, device=st.learned_out.device)
-        ops.masked_correct_pair(st.learned_out, st.random_out, batch.y, batch.train_mask, st.cbuf)
+        # both counts (and, under graph capture, their hand-over to the polling host: gate_publish) in two launches, no zero fill
+        st.cbuf = ops.gate_counts(st.learned_out, st.random_out, batch.y, batch.train_mask, publish=gate_publish)
     return st
 
 
