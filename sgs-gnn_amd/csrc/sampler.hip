@@ -456,13 +456,20 @@ __global__ void __launch_bounds__(kThreads) small_reduce_first(const float* __re
     if (!dyn_range(dynE, E, nblk_)) return;
     const int64_t base = static_cast<int64_t>(blockIdx.x) * kChunk;
     float acc = (MODE == 1) ? -INFINITY : 0.f;
+    // (loads first, unconditional on clamped indices, then the arithmetic: a load under `if (e < E)` with its use inside the branch is
+    //  waited for inside the branch -- the unrolled items went through memory one after the other)
+    float pv[kItems];
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
+        pv[i] = p ? p[e < E ? e : E - 1] : 1.f;
+    }
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
         const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
         if (e < E) {
-            const float v = p ? p[e] : 1.f;
-            if (MODE == 1) acc = fmaxf(acc, v);
-            else acc += v;
+            if (MODE == 1) acc = fmaxf(acc, pv[i]);
+            else acc += pv[i];
         }
     }
     if (MODE == 1) {
@@ -482,10 +489,16 @@ __global__ void __launch_bounds__(kThreads) small_reduce_sumexp(const float* __r
     const float mx = final_reduce_all<1>(part_max, nblk, red);
     const int64_t base = static_cast<int64_t>(blockIdx.x) * kChunk;
     float acc = 0.f;
+    float pv[kItems];
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
         const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
-        if (e < E) acc += expf(p[e] - mx);
+        pv[i] = p[e < E ? e : E - 1];
+    }
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
+        if (e < E) acc += expf(pv[i] - mx);
     }
     const float r = block_sum(acc, red);
     if (threadIdx.x == 0) part_sum[blockIdx.x] = r;
@@ -512,12 +525,21 @@ __global__ void __launch_bounds__(kThreads) small_keys_hist0(const float* __rest
     const float Zeps = (MODE == SGS_SAMPLE_LEARNED) ? __fadd_rn(Z, 1e-12f) : Z;
     const bool has_prior = prior != nullptr;
     const int64_t base = static_cast<int64_t>(blockIdx.x) * (kThreads * kKeyItems);
+    float pv[kKeyItems], qv[kKeyItems], nv[kKeyItems];      // every load of the thread in flight before the first use (see small_reduce_first)
+#pragma unroll
+    for (int i = 0; i < kKeyItems; ++i) {
+        const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
+        const int64_t ec = e < E ? e : E - 1;
+        pv[i] = p ? p[ec] : 1.f;
+        qv[i] = has_prior ? prior[ec] : 0.f;
+        nv[i] = noise ? noise[ec] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < kKeyItems; ++i) {
         const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
         if (e < E) {
-            const float s = sample_prob<MODE>(p ? p[e] : 1.f, Zeps, mx, has_prior ? prior[e] : 0.f, has_prior, one_minus_c, c);
-            const float nz = noise ? noise[e] : exp_noise_at(seed, stream_id, static_cast<uint64_t>(e));
+            const float s = sample_prob<MODE>(pv[i], Zeps, mx, qv[i], has_prior, one_minus_c, c);
+            const float nz = noise ? nv[i] : exp_noise_at(seed, stream_id, static_cast<uint64_t>(e));
             const float key = __fdiv_rn(s, nz);
             const uint32_t bits = __float_as_uint(key);
             keys[e] = bits;
@@ -549,13 +571,16 @@ __global__ void __launch_bounds__(kThreads) small_hist_next(const uint32_t* __re
     if (blockIdx.x == 0 && threadIdx.x == 0) { sel_out->prefix = prefix; sel_out->k_rem = k - f.y; }
     const uint32_t want = prefix >> prev_shift;
     const int64_t base = static_cast<int64_t>(blockIdx.x) * kChunk;
+    uint32_t kv[kItems];
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
         const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
-        if (e < E) {
-            const uint32_t bits = keys[e];
-            if ((bits >> prev_shift) == want) atomicAdd(&lh[(bits >> shift) & digit_mask], 1u);
-        }
+        kv[i] = keys[e < E ? e : E - 1];
+    }
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
+        if (e < E && (kv[i] >> prev_shift) == want) atomicAdd(&lh[(kv[i] >> shift) & digit_mask], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < kBins; i += kThreads) {
