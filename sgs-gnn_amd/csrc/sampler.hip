@@ -534,16 +534,26 @@ __global__ void __launch_bounds__(kThreads) small_keys_hist0(const float* __rest
         qv[i] = has_prior ? prior[ec] : 0.f;
         nv[i] = noise ? noise[ec] : 0.f;
     }
+    // all eight keys in registers BEFORE the first store: vmcnt counts stores too on this target, and behind the per-item branches the
+    // compiler's wait for an item's (long finished) loads was vmcnt(0) -- i.e. for the previous item's key store, eight times over
+    float kf[kKeyItems];
+#pragma unroll
+    for (int i = 0; i < kKeyItems; ++i) {
+        const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
+        kf[i] = 0.f;
+        if (e < E) {
+            const float s = sample_prob<MODE>(pv[i], Zeps, mx, qv[i], has_prior, one_minus_c, c);
+            const float nz = noise ? nv[i] : exp_noise_at(seed, stream_id, static_cast<uint64_t>(e));
+            kf[i] = __fdiv_rn(s, nz);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < kKeyItems; ++i) {
         const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
         if (e < E) {
-            const float s = sample_prob<MODE>(pv[i], Zeps, mx, qv[i], has_prior, one_minus_c, c);
-            const float nz = noise ? nv[i] : exp_noise_at(seed, stream_id, static_cast<uint64_t>(e));
-            const float key = __fdiv_rn(s, nz);
-            const uint32_t bits = __float_as_uint(key);
+            const uint32_t bits = __float_as_uint(kf[i]);
             keys[e] = bits;
-            if (keys_out) keys_out[e] = key;
+            if (keys_out) keys_out[e] = kf[i];
             atomicAdd(&lh[bits >> kShift0], 1u);
         }
     }
