@@ -102,3 +102,18 @@ def test_s4_arxiv_gat_straight_through_step_matches_oracle_at_size():
     torch.manual_seed(3)
     m = S.GATModel(Fin, 256, C, dropout_prob=0.0, edge_mlp_type="GCN").to(DEV)
     _step_vs_oracle(S, b, m, "straight_through", 100_000, gnn=O.gat_forward)
+
+
+def test_s1_smallcora_hybrid_step_matches_oracle_at_size():
+    """Config 1 (BASELINE.json configs[0]; datasets.py:51-54 Planetoid Cora, logs/log_macro.txt:28): N = 2 708, F = 1 433, C = 7,
+    E = 10 556, un-partitioned so q = int(0.2 E) = 2 111 (main.py:54), H = 256, hybrid pipeline, GCN scorer.  E < 65 536: the step
+    runs the small-launch fp32-MFMA scorer (`edge_score_stream_kernel`) forward and the dense-`dv` backward end to end."""
+    import sgs_gnn_amd as S
+    N, Fin, C, E = 2_708, 1_433, 7, 10_556
+    b = S.synthetic_graph(N, E, Fin, C, seed=100, train_frac=0.2, power=0.5, device=DEV)
+    assert b.x.shape == (N, Fin) and abs(b.edge_index.shape[1] - E) <= 2
+    q = int(b.edge_index.shape[1] * 0.2)
+    assert abs(q - 2_111) <= 1
+    torch.manual_seed(1)
+    m = S.GNNModel(Fin, 256, C, dropout_prob=0.0, edge_mlp_type="GCN").to(DEV)
+    _step_vs_oracle(S, b, m, "hybrid", q)
