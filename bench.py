@@ -3,6 +3,7 @@
 Reddit-like METIS-partition stream (20 % of edges kept), on N MI355X of one node.
 
     python bench.py --gpus 1 --steps 230 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          # WORLD_SIZE unset: starts its own N ranks (one fresh process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -20,9 +21,17 @@ timings (`epochs`), per-branch step times (`branch_ms`) and the one-time capture
 Prints ONE JSON line (rank 0).  `value` = learned-sampled edges per second over all ranks
 (q per step whose partition has more than q edges; the prior-only draw is not counted).
 
+Before the timed window one whole epoch of the stream runs untimed (`--settle-epochs`, 0.14 s): the gate moves from "random wins" at
+initialisation to "learned wins" within the first epoch and a learned-branch step costs twice a random-branch one, so a window
+taken right after initialisation flatters the number; `value` is the steady-state figure (`learned_fraction_in_window`).
+
 Other BASELINE.json configurations (one JSON line each, same metric, `config.workload` names them):
     python bench.py --config S2      # CitationFull-Cora-like full graph (N=19 793, F=8 710, E=126 842, q=25 368)
     python bench.py --config S4      # arxiv-year-like partitions, --GNN GAT, straight_through
+    python bench.py --config S5 --gpus N   # ONE full-Reddit-size graph (N=232 965, E=114.6 M, q=22.9 M), edge-partitioned over N
+                                           # ranks: STRONG scaling (N=1 = plain train()); all-reduce form and node-block form
+The default (S3) line carries the S5 record as a sub-object (`s5`; `--s5 0` skips it), so one driver line per N holds both the
+weak-scaling partition stream and the strong-scaling edge-sharded step.
 """
 import argparse
 import contextlib
@@ -320,6 +329,12 @@ def run_s3(a, S, rank, world, device):
     warm = [stream(i) for i in range(a.warmup)]
     timed = [stream(a.warmup + i) for i in range(a.steps)]
     sampled = sum(Q for b in timed if b.edge_index.shape[1] > Q)
+    # untimed: whole epochs of the stream until the gate mix has settled (module docstring); every rank runs the same number of steps
+    settle = []
+    for e in range(a.settle_epochs):
+        so = random.Random(50 + e).sample(range(P), P)
+        r_ = _quiet_train(S, args, 0, 10, *train_args, [pool[i] for i in so], q=Q, alternate_frequency=0)
+        settle.append(r_[2])
     if warm:
         _quiet_train(S, args, 0, 10, *train_args, warm, q=Q, alternate_frequency=0)
     dt, ret = _timed_train(S, world, args, 1, 10, *train_args, timed, q=Q, alternate_frequency=0)
@@ -348,6 +363,7 @@ def run_s3(a, S, rank, world, device):
                    "adam": "sgs_gnn_amd.FusedAdam (in-graph)" if a.fused_adam else "torch.optim.Adam (foreach, eager)"},
         "mean_loss": round(ret[0], 5), "conditional_updates": ret[2], "total_updates": ret[3],
         "learned_fraction_in_window": round(ret[2] / max(n_above, 1), 3),
+        "settle_epochs": a.settle_epochs, "settle_learned_steps": settle,
         "capture_s": round(capture_s, 3), "graph_hbm_GiB": round(graph_hbm / 2**30, 3), "pool_build_s": round(pool_s, 2),
     }
     if world > 1:
@@ -501,12 +517,196 @@ def run_s4(a, S, device):
     return rec
 
 
+# --------------------------------------------------------------------------------------------- S5: one full-size graph, edge-partitioned
+class _CollectiveMeter:
+    """Counts the collectives of ONE step (calls, payload bytes per call) by wrapping torch.distributed's entry points."""
+
+    def __init__(self):
+        self.calls = []
+        self._saved = {}
+
+    def __enter__(self):
+        def wrap(name, nbytes):
+            fn = getattr(dist, name)
+            self._saved[name] = fn
+
+            def counted(*args, **kw):
+                self.calls.append((name, nbytes(*args, **kw)))
+                return fn(*args, **kw)
+            setattr(dist, name, counted)
+        wrap("all_reduce", lambda t, *a_, **k_: t.numel() * t.element_size())
+        wrap("all_gather", lambda out, t, *a_, **k_: t.numel() * t.element_size() * len(out))
+        wrap("reduce_scatter", lambda out, parts, *a_, **k_: sum(x.numel() * x.element_size() for x in parts))
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self._saved.items():
+            setattr(dist, name, fn)
+        return False
+
+    def summary(self):
+        by = {}
+        for name, nb in self.calls:
+            d = by.setdefault(name, {"calls": 0, "bytes": 0, "max_bytes": 0})
+            d["calls"] += 1
+            d["bytes"] += nb
+            d["max_bytes"] = max(d["max_bytes"], nb)
+        return {"calls": len(self.calls), "bytes": sum(nb for _, nb in self.calls), "by_op": by}
+
+
+def run_s5(a, S, rank, world, device, steps=None, warmup=None):
+    """BASELINE.json config 5: ONE Reddit-size graph (N = 232 965, F = 602, C = 41, E = 114.6 M candidate edges, q = 0.2 E = 22.9 M,
+    main.py:54 un-partitioned), hybrid pipeline.  STRONG scaling: the same graph at every N.  N = 1: the plain single-GPU train()
+    (eager launches -- a step is ~0.1-0.2 s of GPU work).  N > 1: the edge list is cut into N contiguous shards (sharded.py) and the
+    step runs in both forms -- `train_step_sharded` (RCCL all-reduce of the [N, D] node embeddings, what north_star names) and
+    `train_step_blocksharded` (node-block form: reduce-scatter forward / all-gather backward)."""
+    from sgs_gnn_amd import sharded as sh
+    steps = steps if steps is not None else a.steps
+    warmup = warmup if warmup is not None else a.warmup
+    N, F_, C, H = 232_965, NFEAT, NCLS, HID
+    e_target = int(os.environ.get("SGS_BENCH_S5_EDGES", "114615892"))
+    t0 = time.perf_counter()
+    b = S.synthetic_graph(N, e_target, F_, C, seed=77, train_frac=0.66, power=0.35, device=device)     # same seed: every rank builds the same graph
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    E = b.edge_index.shape[1]
+    q = int(E * 0.2)
+    args = make_args(device)
+    crit = torch.nn.CrossEntropyLoss()
+
+    def fresh():
+        S.fix_seeds(1)
+        return build_model(S, device, fused=True)
+
+    def timed_steps(one_step):
+        for _ in range(warmup):
+            one_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = [one_step() for _ in range(steps)]
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt, _ = _reduce(world, device, time.perf_counter() - t0, 0)
+        return dt, outs
+
+    forms = {}
+    if world == 1:
+        model, og, oe, oa = fresh()
+        ep = [0]
+
+        def one():
+            r = _quiet_train(S, args, ep[0], 10, model, og, oe, oa, crit, [b], q=q)
+            ep[0] += 1
+            return bool(r[2])
+        dt, outs = timed_steps(one)
+        forms["single_gpu_train"] = {"step_s": round(dt / steps, 5), "sampled_edges_per_s": round(q * steps / dt, 1), "learned_steps": sum(outs),
+                                     "steps": steps}
+    else:
+        shard = sh.EdgeShard(b, rank, world)
+        b.edge_index = b.prob = None                 # the shard holds this rank's slice; node data stay replicated
+        torch.cuda.empty_cache()
+        for name, fn in (("allreduce", sh.train_step_sharded), ("nodeblock", sh.train_step_blocksharded)):
+            model, og, oe, oa = fresh()
+
+            def one(fn=fn, model=model, og=og, oe=oe):
+                return bool(fn(args, model, shard, og, oe, crit, q)["update_edge_mlp"])
+            dt, outs = timed_steps(one)
+            with _CollectiveMeter() as cm:
+                learned = one()
+            torch.cuda.synchronize()
+            forms[name] = {"step_s": round(dt / steps, 5), "sampled_edges_per_s": round(q * steps / dt, 1), "learned_steps": sum(outs), "steps": steps,
+                           "collectives_one_step": dict(cm.summary(), learned_branch=learned)}
+    best = min(forms, key=lambda k: forms[k]["step_s"])
+    rec = {"workload": f"full-Reddit-size graph (S5): N={N} F={F_} C={C} H={H} E={E} q={q}, hybrid pipeline, EdgeProbGCN scorer, conditional "
+                       f"gate, reg1+reg2, dropout 0.3, FusedAdam x2; one step per epoch (main.py:67); synthetic",
+           "scaling": "strong", "n_gpus": world, "steps": steps, "warmup": warmup, "best_form": best, "step_s": forms[best]["step_s"],
+           "sampled_edges_per_s": forms[best]["sampled_edges_per_s"], "steps_per_s": round(1.0 / forms[best]["step_s"], 3), "forms": forms,
+           "graph_build_s": round(build_s, 2), "peak_hbm_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+           "edges_per_rank": int(E // world)}
+    if world > 1:
+        rec["collective_backend"], rec["collective_ranks"] = dist.get_backend(), dist.get_world_size()
+    del b
+    torch.cuda.empty_cache()
+    return rec
+
+
+def s5_line(a, S, rank, world, device):
+    """`--config S5` as its own bench line (same metric; strong scaling)."""
+    r = run_s5(a, S, rank, world, device)
+    best = r["forms"][r["best_form"]]
+    rec = {"metric": METRIC, "value": r["sampled_edges_per_s"], "unit": "sampled edges/s", "steps_per_s": r["steps_per_s"], "n_gpus": world,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(best["step_s"] * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": r["workload"], "parallelism": (f"edge-partitioned over {world} ranks, form '{r['best_form']}'" if world > 1 else "single"),
+                      "hipgraph_replay": False},
+           "s5": r}
+    return rec
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with WORLD_SIZE unset: start N fresh rank processes (this very command line, one per GPU) and relay
+    rank 0's JSON line.  The parent makes NO GPU call, before or after (device_count() does not initialise the runtime on this
+    image); nothing is re-exec'ed.  A failing rank takes the others down (exact PIDs) and the parent exits non-zero."""
+    import subprocess
+    import tempfile
+    rehearse = os.environ.get("SGS_BENCH_REHEARSE") == "1"
+    have = torch.cuda.device_count()
+    if not rehearse and have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible (SGS_BENCH_REHEARSE=1 runs all ranks on cuda:0 over gloo)")
+    port = _free_port()
+    procs, outs = [], []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        out = tempfile.TemporaryFile(mode="w+") if r == 0 else subprocess.DEVNULL
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for p in procs:
+            if p.poll() not in (None, 0):
+                failed = p.returncode
+        time.sleep(0.05)
+    if failed is None:
+        failed = next((p.returncode for p in procs if p.returncode != 0), None)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except Exception:
+                p.kill()
+    outs[0].seek(0)
+    sys.stdout.write(outs[0].read())
+    sys.stdout.flush()
+    if failed is not None:
+        raise SystemExit(failed if failed > 0 else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=230, help="timed steps (default: one epoch of the 230-partition stream)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="S3", choices=["S3", "S2", "S4"])
+    ap.add_argument("--config", default="S3", choices=["S3", "S2", "S4", "S5"])
+    ap.add_argument("--settle-epochs", type=int, default=1, help="S3: untimed whole epochs before the timed window (the gate mix settles within the first)")
+    ap.add_argument("--s5", type=int, default=1, help="S3: 1 (default) also runs config 5 (one full-size graph, edge-partitioned over the ranks; "
+                    "strong scaling) and reports it as the `s5` sub-object; 0: skip")
+    ap.add_argument("--s5-steps", type=int, default=3, help="timed steps per form of the `s5` sub-object (after 1 warm-up step)")
     ap.add_argument("--parts", type=int, default=230, help="S3: partitions of the stream kept resident per rank")
     ap.add_argument("--epochs", type=int, default=2, help="S3, one GPU: additional whole-epoch timings")
     ap.add_argument("--diag-steps", type=int, default=48, help="S3, one GPU: synchronised single steps for the per-branch times")
@@ -524,9 +724,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(a.gpus)             # the parent only launches and collects: no GPU call in this process
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"bench.py --gpus {a.gpus} inside a {world}-rank launch: pass the launcher's rank count")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the SGS hot path has no CPU fallback")
     # rehearsal on a one-GPU box (SGS_BENCH_REHEARSE=1): every rank on cuda:0 over gloo -- exercises the N > 1 code path
@@ -549,6 +750,14 @@ def main():
     S.fix_seeds(42 + rank)
     if a.config == "S3":
         rec = run_s3(a, S, rank, world, device)
+        if a.s5:
+            s5 = run_s5(a, S, rank, world, device, steps=a.s5_steps, warmup=1)
+            if rank == 0:
+                rec["s5"] = s5
+    elif a.config == "S5":
+        if a.steps == 230:
+            a.steps, a.warmup = 6, 2
+        rec = s5_line(a, S, rank, world, device)
     else:
         if world > 1:
             raise SystemExit("--config S2 / S4 are single-GPU lines")
