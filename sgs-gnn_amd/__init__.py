@@ -9,6 +9,6 @@ from .scorer import EdgeProbGCN, EdgeProbMLP, EdgeProbSAGE, SAGEConv, get_edge_m
 from .sampling import gumbel_softmax_sampling, random_edge_sampling, manual_seed  # noqa: F401
 from .training import train, train_hybrid, train_straight_through, train_two_pass, prepare_step_graphs  # noqa: F401
 from .evaluate import evaluate, ensemble_evaluate  # noqa: F401
-from .utils import calculate_f1, consistency_loss, fix_seeds  # noqa: F401
+from .utils import calculate_f1, consistency_loss, fix_seeds, GpuMemoryProfiler  # noqa: F401
 from .optim import FusedAdam  # noqa: F401
 from .data import Batch, ResidentPartitions, degree_prior, synthetic_graph, reddit_partition_stream, reddit_partition_sizes  # noqa: F401

@@ -93,12 +93,14 @@ class GNNModel(nn.Module):
         self.gcn2 = GCNConv(hidden_dim, num_classes)
 
     def forward(self, data, edge_index, edge_weight=None):
+        from .utils import segment
         x = data.x
-        norm = ops.gcn_norm(ops.get_graph(edge_index, x.shape[0]), edge_weight)   # once for both layers
-        p = self.dropout.p if self.training else 0.0
-        act = ops.ACT_RELU_DROPOUT if p > 0 else ops.ACT_RELU
-        h = self.gcn1(x, edge_index, norm=norm, act=act, p=p, seed=_DropoutClock.next_seed(), site=SITE_GNN)
-        return self.gcn2(h, edge_index, norm=norm)
+        with segment(self, "gnn_forward"):                        # model.py:156-163
+            norm = ops.gcn_norm(ops.get_graph(edge_index, x.shape[0]), edge_weight)   # once for both layers
+            p = self.dropout.p if self.training else 0.0
+            act = ops.ACT_RELU_DROPOUT if p > 0 else ops.ACT_RELU
+            h = self.gcn1(x, edge_index, norm=norm, act=act, p=p, seed=_DropoutClock.next_seed(), site=SITE_GNN)
+            return self.gcn2(h, edge_index, norm=norm)
 
 
 # ------------------------------------------------------------------ GAT head (model.py:189-208)
@@ -168,7 +170,9 @@ class GATModel(nn.Module):
                        dropout=dropout_prob, act='relu')
 
     def forward(self, data, edge_index, edge_weight=None):
-        return self.GAT(data.x, edge_index, edge_weight=edge_weight)
+        from .utils import segment
+        with segment(self, "gnn_forward"):
+            return self.GAT(data.x, edge_index, edge_weight=edge_weight)
 
 
 # ------------------------------------------------------------------ GIN head (model.py:165-184)
@@ -233,7 +237,9 @@ class GINModel(nn.Module):
                        dropout=dropout_prob, act='relu')
 
     def forward(self, data, edge_index, edge_weight=None):
-        return self.GIN(data.x, edge_index, edge_weight=edge_weight)
+        from .utils import segment
+        with segment(self, "gnn_forward"):
+            return self.GIN(data.x, edge_index, edge_weight=edge_weight)
 
 
 # ------------------------------------------------------------------ Chebyshev head (model.py:211-230)

@@ -4,6 +4,8 @@ and autograd bookkeeping only; every numeric step of the hot path runs in libsgs
 Nothing here computes on the CPU: a non-HIP tensor raises."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -69,9 +71,47 @@ class workspace_slot:
         return False
 
 
+# Stream ownership of the arenas.  An arena is reused in STREAM ORDER: two kernels that take scratch from the same slot are safe only
+# if one stream orders them.  Round 2 lost a bench run to exactly this (a partition's CSR build issued on the prefetch stream took
+# scratch from arena 0 while the replayed step's sampler was using it) and fixed it by convention.  The
+# guard makes the convention checkable: each slot remembers the raw stream that last took scratch from it, and -- with
+# SGS_WS_GUARD=1 (the test suite sets it) -- a request from ANOTHER stream raises, unless the caller declared the hand-over
+# (`workspace_handover`: "the current stream has been ordered after the owner", e.g. right after stream.wait_stream(owner)).
+_ws_owner = {}
+_ws_guard = os.environ.get("SGS_WS_GUARD") == "1"
+
+
+def set_workspace_guard(on: bool) -> None:
+    global _ws_guard
+    _ws_guard = bool(on)
+    _ws_owner.clear()
+
+
+def workspace_handover(device=None, slot=None) -> None:
+    """The caller has made the CURRENT stream wait for everything issued so far on this device's arenas' owners (wait_stream /
+    wait_event / a device synchronisation): the current stream owns every slot (or just `slot`) from here on."""
+    if not _ws_guard:
+        return
+    dev = torch.cuda.current_device() if device is None else (device.index if device.index is not None else torch.cuda.current_device())
+    cur = _stream()
+    if slot is not None:
+        _ws_owner[(dev, int(slot))] = cur
+        return
+    for key in list(_ws_owner):
+        if key[0] == dev:
+            _ws_owner[key] = cur
+
+
 def workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only per-device scratch arena (stream-ordered reuse on the current stream; see workspace_slot)."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), _ws_slot)
+    if _ws_guard:
+        cur = _stream()
+        own = _ws_owner.setdefault(key, cur)
+        if own != cur:
+            raise RuntimeError(f"sgs_gnn_amd: scratch arena {key[1]} of device {key[0]} is owned by stream {own:#x} and was asked for from stream "
+                               f"{cur:#x} without a hand-over (ops.workspace_handover): kernels on two streams would share scratch memory; "
+                               "use ops.workspace_slot(k) for work that runs beside the main stream")
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         if ws is not None and _pin_workspaces:

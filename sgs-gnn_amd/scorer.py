@@ -7,6 +7,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .model import GCNConv, _DropoutClock, SITE_ENC, SITE_SCORE, SITE_MLP_X, SITE_MLP_Y
+from .utils import segment
 
 
 class EdgeProbGCN(nn.Module):
@@ -27,14 +28,16 @@ class EdgeProbGCN(nn.Module):
         # the [E,2H]/[E,H] activations and always recomputes them in backward.
         g = random_sampled_edge_index if random_sampled_edge_index is not None else edge_index
         N = node_features.shape[0]
-        norm = ops.gcn_norm(ops.get_graph(g, N), None)
         p = self.dropout.p if self.training else 0.0
         act = ops.ACT_RELU_DROPOUT if p > 0 else ops.ACT_RELU
-        out = self.gcn1(node_features, g, norm=norm, act=act, p=p, seed=_DropoutClock.next_seed(), site=SITE_ENC)
-        out = self.gcn2(out, g, norm=norm, act=ops.ACT_RELU)
+        with segment(self, "edge_mlp_pre"):                       # model.py:103-112
+            norm = ops.gcn_norm(ops.get_graph(g, N), None)
+            out = self.gcn1(node_features, g, norm=norm, act=act, p=p, seed=_DropoutClock.next_seed(), site=SITE_ENC)
+            out = self.gcn2(out, g, norm=norm, act=ops.ACT_RELU)
         self.last_active = ops.ActiveSet()
-        prob = ops.edge_score(out, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, edge_index,
-                              active=self.last_active, p=p, seed=_DropoutClock.next_seed(), site=SITE_SCORE)
+        with segment(self, "edge_score"):                         # model.py:124-131
+            prob = ops.edge_score(out, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, edge_index,
+                                  active=self.last_active, p=p, seed=_DropoutClock.next_seed(), site=SITE_SCORE)
         return prob.unsqueeze(1)
 
 
@@ -114,10 +117,12 @@ class EdgeProbSAGE(nn.Module):
         g = random_sampled_edge_index if random_sampled_edge_index is not None else edge_index
         p = self.dropout.p if self.training else 0.0
         act = ops.ACT_RELU_DROPOUT if p > 0 else ops.ACT_RELU
-        out = self.gcn1(node_features, g, act=act, p=p, seed=_DropoutClock.next_seed(), site=SITE_ENC)
+        with segment(self, "edge_mlp_pre"):                       # model.py:59-66
+            out = self.gcn1(node_features, g, act=act, p=p, seed=_DropoutClock.next_seed(), site=SITE_ENC)
         self.last_active = ops.ActiveSet()
-        prob = ops.edge_score(out, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, edge_index,
-                              active=self.last_active, p=p, seed=_DropoutClock.next_seed(), site=SITE_SCORE)
+        with segment(self, "edge_score"):                         # model.py:80-87
+            prob = ops.edge_score(out, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, edge_index,
+                                  active=self.last_active, p=p, seed=_DropoutClock.next_seed(), site=SITE_SCORE)
         return prob.unsqueeze(1)
 
 

@@ -460,6 +460,8 @@ class StepGraphs:
         t0 = time.perf_counter()
         cur = torch.cuda.current_stream()
         self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            ops.workspace_handover(self.device)          # the capture stream is ordered after the main stream: it owns the arenas now
         ops.set_dyn_edges(slot.dims)        # kernels over the candidate edges read the live count from the slot (min rule, sgs_hip.h)
         from .model import _DropoutClock
         from .sampling import _NoiseClock
@@ -482,6 +484,7 @@ class StepGraphs:
             self._clear_grads()
             cur.wait_stream(self.stream)
             torch.cuda.synchronize()
+            ops.workspace_handover(self.device)          # ... and back (everything on the capture stream has finished)
             self.capture_seconds += time.perf_counter() - t0
             self.captures += 1
             if was_enabled:
@@ -676,7 +679,12 @@ class StepGraphs:
         if want_next:
             self.ev_main.record(main)                  # the next partition's hand-over may start once everything before THIS G1 is done
         seq0 = int(self.host_gate_np[4])
+        prof = getattr(self.model, "gpu_profiler", None)
+        if prof is not None:
+            prof.begin("replay:G1" if c.sampled else "replay:G")      # the reference's forward segments are inside this replay
         c.g1.replay()
+        if prof is not None:
+            prof.end("replay:G1" if c.sampled else "replay:G")
         if want_next:
             self._prefetch(next_batch, self.ev_main, avoid=c)
         return _ReplayHandle(self, c, seq0)
@@ -714,13 +722,14 @@ class StepGraphs:
 
 
 class _ReplayHandle:
-    __slots__ = ("sg", "c", "sampled", "cbuf", "opt_in_graph", "seq0", "loss_on_device")
+    __slots__ = ("sg", "c", "sampled", "cbuf", "opt_in_graph", "seq0", "loss_on_device", "dp_in_handle")
 
     def __init__(self, sg, c, seq0):
         self.sg, self.c, self.sampled, self.cbuf = sg, c, c.sampled, c.cbuf
         self.opt_in_graph = sg.optimizers is not None      # the backward graphs (or, data-parallel, g3) hold the optimiser steps
         self.seq0 = seq0
         self.loss_on_device = True                         # the graphs add their loss to sg.loss_sum
+        self.dp_in_handle = sg.dp                          # data parallel: backward() issues the bucket all-reduce and replays g3
 
     def gate_counts(self):
         """[#correct learned, #train, #correct random, #train] of this replay: polls the pinned gate words G1 publishes
@@ -755,13 +764,18 @@ class _ReplayHandle:
 
 
 class _EagerHandle:
-    """A batch the slots cannot take (no edges, another feature width): the same segments launched eagerly."""
-    __slots__ = ("sg", "batch", "sampled", "cbuf", "st", "opt_in_graph", "loss_on_device")
+    """A batch the slots cannot take (no edges, another feature width): the same segments launched eagerly.
+    Data-parallel graph mode: this rank's peers replay their steps, i.e. they issue [gate sum,] ONE all-reduce of the flat bucket
+    (gradients + "this rank learned" word) and then the shared optimiser graph g3.  The eager step must join exactly those
+    collectives -- a different sequence (a flag all-reduce, GradSync.sync) would pair up with the wrong calls on the other ranks --
+    so its backward writes the gradients and the flag into the bucket, all-reduces it and replays g3 as well."""
+    __slots__ = ("sg", "batch", "sampled", "cbuf", "st", "opt_in_graph", "loss_on_device", "dp_in_handle")
 
     def __init__(self, sg, batch):
         from .training import sampled_forward
         self.sg, self.batch = sg, batch
-        self.opt_in_graph = False
+        self.opt_in_graph = sg.dp                          # data parallel: g3 steps the optimisers
+        self.dp_in_handle = sg.dp
         self.loss_on_device = False
         self.sampled = batch.edge_index.shape[1] > sg.q
         self.cbuf, self.st = None, None
@@ -781,4 +795,24 @@ class _EagerHandle:
             loss = learned_loss(a, sg.criterion, st, batch) if (learned or st.random_out is None) else _ce(sg.criterion, st.random_out, batch)
         loss.backward()
         self.st = None
+        if sg.dp:
+            sy = sg.sync
+            sy._ensure(sg.device)
+            if sg.g3 is None:
+                sg._capture_g3()
+            have_v, have_g, miss_v = [], [], []
+            for p, v in zip(sy.params, sy.views):
+                if p.grad is None:
+                    miss_v.append(v)
+                else:
+                    have_v.append(v)
+                    have_g.append(p.grad)
+            if have_v:
+                torch._foreach_copy_(have_v, have_g)
+            if miss_v:
+                torch._foreach_zero_(miss_v)
+            sy.flag.fill_(1.0 if (self.sampled and (learned or st.random_out is None)) else 0.0)
+            sg._clear_grads()                              # g3 reads the bucket's views, which it was captured over
+            sy.all_reduce_bucket()
+            sg.g3.replay()
         return loss.detach()

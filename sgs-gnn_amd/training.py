@@ -21,6 +21,7 @@ import torch.nn as nn
 from . import ops
 from .dist import GradSync, is_parallel
 from .sampling import draw_learned, draw_prior, random_edge_sampling
+from .utils import segment
 
 _PIPELINES = ("two_pass", "straight_through", "hybrid")
 
@@ -34,6 +35,12 @@ def _ce(criterion, out, batch):
     if _fused_ce_ok(criterion):
         return ops.masked_cross_entropy(out, batch.y, batch.train_mask)
     return criterion(out[batch.train_mask], batch.y[batch.train_mask])      # user-supplied criterion: run as given
+
+
+def _backward(model, loss):
+    """training_hybrid.py:22-27: loss.backward() inside the profiler's "backward" segment (a rocTX range, utils.GpuMemoryProfiler)."""
+    with segment(model, "backward"):
+        loss.backward()
 
 
 def _has_train_nodes(batch) -> bool:
@@ -92,7 +99,8 @@ def sampled_forward(pipeline, args, model, batch, q, use_checkpoint=False, noise
         ops.gcn_norm(ops.get_graph(st.rsei, N), None)                 # CSR + unit normalisation of the random graph: shared, built before the fork
         main_stream = torch.cuda.current_stream()
         side_stream.wait_stream(main_stream)
-        with torch.cuda.stream(side_stream):
+        with torch.cuda.stream(side_stream), ops.workspace_slot(2):      # beside the main stream: its own scratch arena
+            ops.workspace_handover(batch.x.device, slot=2)
             st.random_out = model(batch, st.rsei)
 
     # pass 1: score every edge (hybrid / ST with grad, two-pass without)
@@ -327,7 +335,7 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
             eager_opt = h is None or not h.opt_in_graph       # capturable optimisers are stepped inside the backward graph
             # N > 1 with FusedAdam: a replayed step all-reduces the gradient bucket and replays the optimiser graph inside
             # h.backward(); the "any rank learned" word travels in that bucket and is read on the device
-            fused_dp = h is not None and graphs.dp and h.loss_on_device
+            fused_dp = h is not None and graphs.dp and h.dp_in_handle
             global_gate = bool(getattr(args, "sgs_dp_global_gate", False))
             esync = sync if not fused_dp else None            # the eager collectives below are for every other case
             sampled = h.sampled if h is not None else batch.edge_index.shape[1] > q
@@ -365,9 +373,10 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
                     condtional_update += 1
                     if h is None:
                         loss = learned_loss(args, criterion, st, batch)
-                        loss.backward()
+                        _backward(model, loss)
                     else:
-                        loss = h.backward(True)
+                        with segment(model, "backward"):
+                            loss = h.backward(True)
                     if esync is not None:
                         esync.sync()
                     if eager_opt:
@@ -376,9 +385,10 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
                 else:
                     if h is None:
                         loss = _ce(criterion, st.random_out, batch)
-                        loss.backward()
+                        _backward(model, loss)
                     else:
-                        loss = h.backward(False)
+                        with segment(model, "backward"):
+                            loss = h.backward(False)
                     if esync is not None:
                         esync.sync(all_random=not any_learned)
                         if any_learned:
@@ -397,9 +407,10 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
                 if h is None:
                     out = model(batch, batch.edge_index)
                     loss = _ce(criterion, out, batch)
-                    loss.backward()
+                    _backward(model, loss)
                 else:
-                    loss = h.backward(None)
+                    with segment(model, "backward"):
+                        loss = h.backward(None)
                 if esync is not None:
                     # every rank is in lock-step on the partition stream, so ranks whose partition is small
                     # (no sampling, no gate) still join the flag all-reduce and the gradient all-reduce
@@ -418,7 +429,7 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
             else:
                 out = model(batch, batch.edge_index)
             loss = _ce(criterion, out, batch)
-            loss.backward()
+            _backward(model, loss)
             if sync is not None:
                 sync.sync()
             optimizer.step()
@@ -430,7 +441,7 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
             else:
                 out = model(batch, batch.edge_index)
             loss = _ce(criterion, out, batch)
-            loss.backward()
+            _backward(model, loss)
             if sync is not None:
                 sync.sync()
             optimizer.step()
@@ -439,7 +450,7 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
             batch = batch.to(device)
             out = model(batch, batch.edge_index)
             loss = _ce(criterion, out, batch)
-            loss.backward()
+            _backward(model, loss)
             if sync is not None:
                 sync.sync()
             optimizer.step()

@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# every test runs with the scratch-arena stream guard on (ops.workspace: a slot asked for from a stream that does not own it raises)
+os.environ.setdefault("SGS_WS_GUARD", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

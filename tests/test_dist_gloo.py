@@ -1,6 +1,8 @@
 """CPU, world_size 2 over gloo: the N > 1 host logic (partition sharding + the flat-bucket gradient
 average with the gate flag).  The HIP compute is not involved here."""
 import os
+
+import pytest
 import socket
 
 import torch
@@ -129,3 +131,21 @@ def test_bench_pool_is_dealt_out_by_size_across_ranks():
     assert S.reddit_partition_sizes(12, seed=1000, q=B.Q) == S.reddit_partition_sizes(24, seed=1000, q=B.Q)[:12]
     parts = S.reddit_partition_stream(num_parts=6, seed=1000, nfeat=8, ncls=3, n=50, e_lo=100, e_hi=400, q=200, only={1, 4})
     assert [p is not None for p in parts] == [False, True, False, False, True, False]
+
+
+def test_bench_self_launcher_starts_ranks_and_propagates_failure():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts its own rank processes (no GPU call in the parent, nothing
+    re-exec'ed).  In the build container there is no GPU: every rank exits with bench.py's "needs an MI355X" message, and the parent
+    must come back promptly with a non-zero status instead of a JSON line."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SGS_BENCH_REHEARSE="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    if torch.cuda.is_available():
+        pytest.skip("failure propagation is checked where the ranks cannot find a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs an MI355X" in r.stderr and r.stdout.strip() == ""

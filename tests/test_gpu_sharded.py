@@ -113,7 +113,7 @@ def test_sharded_draw_and_forward_are_rank_count_invariant():
             torch.testing.assert_close(pt["fwd"]["out"], base["out"], rtol=1e-4, atol=1e-5)
 
 
-def _dp_worker(rank, world, port, q_out, hipgraph=False, global_gate=False, uneven=False):
+def _dp_worker(rank, world, port, q_out, hipgraph=False, global_gate=False, uneven=False, empty=False):
     import sys
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -137,6 +137,10 @@ def _dp_worker(rank, world, port, q_out, hipgraph=False, global_gate=False, unev
         batches = [S.synthetic_graph(300, e, 12, 5, seed=10 * rank + i, train_frac=0.5, device=DEV) for i, e in enumerate(sizes)]
         if uneven and rank == 1:
             batches[1].train_mask = torch.zeros_like(batches[1].train_mask)     # a batch the trainer skips on this rank only
+        if empty and rank == 1:
+            # a partition without a single intra-partition edge: the captured slots cannot take it, the step is launched eagerly
+            batches[0].edge_index = torch.zeros(2, 0, dtype=torch.int64, device=DEV)
+            batches[0].prob = torch.zeros(0, dtype=torch.float32, device=DEV)
         args = argparse.Namespace(device=DEV, mode="learned", pipeline="hybrid", conditional=True, sparse_edge_mlp=True, t_init=0.7,
                                   t_min=0.5, degree_bias_coef=0.3, reg1=True, reg2=True, regularizer1_coef=1.0,
                                   consist_reg_coef=0.5, hybrid_checkpoint=False, sgs_hipgraph=hipgraph, sgs_dp_global_gate=global_gate)
@@ -191,6 +195,31 @@ def test_data_parallel_uneven_shards_finish_with_null_steps(hipgraph):
         p.join(120)
         assert p.exitcode == 0
     assert got[0][2] == 4 and got[1][2] == 2
+    for k in got[0][0]:
+        a, b = torch.from_numpy(got[0][0][k]), torch.from_numpy(got[1][0][k])
+        assert torch.equal(a, b), k
+        assert bool(torch.isfinite(a).all())
+
+
+@pytest.mark.parametrize("global_gate", [False, True])
+def test_data_parallel_graph_mode_with_a_batch_the_slots_cannot_take(global_gate):
+    """Graph-mode data parallel where one rank meets a partition without edges (stepgraph._EagerHandle): that rank's eager step must
+    issue exactly the collectives its peer's replayed step issues ([gate sum,] ONE bucket all-reduce, then the shared optimiser
+    graph) -- no hang, no mixed-up reductions, replicas bit-identical."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, True, global_gate, False, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, sd, cond, tot = q.get(timeout=300)
+        got[rank] = (sd, cond, tot)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert got[0][2] == got[1][2] == 3
     for k in got[0][0]:
         a, b = torch.from_numpy(got[0][0][k]), torch.from_numpy(got[1][0][k])
         assert torch.equal(a, b), k

@@ -469,3 +469,79 @@ def test_replayed_step_at_the_benchmarked_shape_matches_its_eager_recomputation(
             assert len(sizes) == 2 and sizes[1] < sizes[0]                               # the smaller partition came AFTER the larger one in that slot
     finally:
         sg.release()
+
+
+def test_workspace_guard_and_first_visit_prefetch_of_an_unscannable_loader():
+    """(1) The scratch-arena guard: a slot is owned by the stream that last took scratch from it; another stream asking for it raises
+    unless the hand-over was declared (the fault of round 2's first bench -- a CSR build on the prefetch stream sharing arena 0 with
+    the replayed step's sampler -- now raises instead of corrupting memory).  (2) The path that used to do it: a loader that
+    reserve() cannot scan (a generator), so a partition's FIRST hand-over happens in _prefetch(): its CSR / mates are built on the
+    main stream, only the copy runs on the prefetch stream.  With the guard on, an epoch over such a loader must pass and train."""
+    import sgs_gnn_amd as S
+    ops = S.ops
+    assert ops._ws_guard, "tests/conftest.py switches the guard on before the package is imported"
+    dev = torch.device(DEV)
+    ops.workspace(1024, dev)                                   # owned by the current (default) stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with pytest.raises(RuntimeError, match="hand-over"):
+            ops.workspace(1024, dev)
+        with ops.workspace_slot(7):                            # its own arena: fine
+            ops.workspace(1024, dev)
+        side.wait_stream(torch.cuda.default_stream())
+        ops.workspace_handover(dev)                            # declared: the side stream owns the arenas now
+        ops.workspace(1024, dev)
+    with pytest.raises(RuntimeError, match="hand-over"):
+        ops.workspace(1024, dev)                               # ... and the default stream has to take them back the same way
+    torch.cuda.current_stream().wait_stream(side)
+    ops.workspace_handover(dev)
+    ops.workspace(1024, dev)
+
+    crit = torch.nn.CrossEntropyLoss()
+    q = 1000
+    m, og, oe = _setup(S, 0.3)
+    og = S.FusedAdam([p for n, p in m.named_parameters() if "gcn" in n], lr=1e-2)
+    oe = S.FusedAdam([p for n, p in m.named_parameters() if "edge_prob_mlp" in n], lr=1e-2)
+    a = _args(sgs_hipgraph=True)
+    sizes = [5000, 900, 4000, 6000, 800, 4500, 5200]
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    for ep in range(2):
+        # fresh batch OBJECTS every epoch, produced lazily: nothing is cached on them ahead of their first hand-over
+        loader = (S.synthetic_graph(150, E, 24, 5, seed=200 + 10 * ep + i, device=DEV) for i, E in enumerate(sizes))
+
+        class Gen:
+            def __iter__(self_):
+                return loader
+
+            def __len__(self_):
+                return len(sizes)
+        loss, _, cond, tot = S.train(a, ep, 2, m, og, oe, None, crit, Gen(), q=q)
+        assert tot == len(sizes) and loss == loss
+    sg = m._sgs_stepgraphs
+    assert sg.last_pre is not None                             # hand-overs did go through the prefetch stream
+    assert any(not torch.equal(p, before[n]) for n, p in m.named_parameters())
+
+
+def test_profiler_segments_are_the_references_and_emit_roctx_ranges():
+    """model.gpu_profiler / model.edge_prob_mlp.gpu_profiler (main.py:116-119): begin / end around the reference's four segments
+    (`edge_mlp_pre`, `edge_score`, `gnn_forward`, `backward`), each also a rocTX range; summary keys as utils.py:51-74."""
+    import sgs_gnn_amd as S
+    from sgs_gnn_amd.utils import SEGMENTS, _RocTx
+    assert _RocTx.lib() is not None
+    crit = torch.nn.CrossEntropyLoss()
+    b = _batches(S, [4000])[0]
+    m, og, oe = _setup(S, 0.3)
+    prof = S.GpuMemoryProfiler(enabled=True, device=DEV)
+    assert prof.enabled
+    m.gpu_profiler = prof
+    m.edge_prob_mlp.gpu_profiler = prof
+    prof.start_epoch(0)
+    S.train(_args(), 0, 1, m, og, oe, None, crit, [b], q=800)
+    summ = prof.summarize_epoch(0)
+    prof.end_epoch()
+    assert set(summ) == set(SEGMENTS)
+    assert summ["edge_mlp_pre"]["calls"] == 1 and summ["edge_score"]["calls"] == 1 and summ["backward"]["calls"] == 1
+    assert summ["gnn_forward"]["calls"] == 2                   # learned + random forward (training_hybrid.py:88,93)
+    for d in summ.values():
+        assert {"max_peak_inc_bytes", "max_peak_inc_mb", "mean_peak_inc_mb", "max_alloc_after_mb", "max_alloc_inc_mb", "calls"} <= set(d)
+    assert summ["edge_score"]["max_peak_inc_bytes"] > 0
