@@ -387,6 +387,26 @@ int sgs_edge_score_bwd_prep(const float* codes, int64_t N, int64_t H, const int6
                             float* feat, sgs_stream_t stream);
 int sgs_edge_score_dw2_from_parts(const float* W1, const float* T_raw, const float* U, const float* R_raw, const float* b1, const float* c_raw,
                                   int64_t N, int64_t H, float p_drop, float* dw2, sgs_stream_t stream);
+/* FUSED form of the same backward (round 3), for active rows SORTED BY SOURCE (a drawn subset of a row-sorted edge list, in edge order: every
+ * dataset of the reference, datasets.py:189-190 to_undirected emits a coalesced list).  Neither feat nor dfeat exists as an [n, H] array:
+ *   sgs_edge_score_bwd_prep_sd        as sgs_edge_score_bwd_prep without feat; sd [n, 2] int32 = the endpoints of every active row
+ *   sgs_edge_score_bwd_dfeat_fused    the dfeat contraction with the by-source half of d codes reduced in its epilogue:
+ *                                       G [n, H] = dfeat * codes[src]  (for the by-destination half),
+ *                                       opart [sgs_edge_score_bwd_fused_opart_rows(n, N), H]: row (r >> 5) + src(r) = the sum of dfeat * codes[dst]
+ *                                       over the rows of src(r) inside 32-row tile r >> 5, written by the LAST such row (other rows of opart: undefined)
+ *   sgs_gemm_tn_mask_gather           d W1a with feat = codes[src] * codes[dst] gathered per row (gemm_tn section below)
+ *   sgs_edge_score_bwd_reduce_fused   d codes[v] = sum of v's opart rows + sum_{in-row v} G;  d U / out_U_raw as sgs_endpoint_reduce_pair_bits
+ * Results equal the unfused entry points' up to fp32 summation order.  HBM traffic at n = 100 000, H = 256: ~0.5 GB -> ~0.22 GB. */
+int sgs_edge_score_bwd_prep_sd(const float* codes, int64_t N, int64_t H, const int64_t* edge_index, int64_t E, const int64_t* active_eid,
+                               int64_t n_active, const float* grad_p, const float* p, const uint32_t* maskbits, float* dz, uint32_t* dvbits,
+                               int32_t* sd, sgs_stream_t stream);
+size_t sgs_edge_score_bwd_fused_opart_rows(int64_t n, int64_t N);
+int sgs_edge_score_bwd_dfeat_fused(const uint32_t* dvbits, const float* dz, const int32_t* sd, const float* codes, int64_t n, int64_t N, int64_t H,
+                                   const float* W1, const float* w2, float p_drop, float* G, float* opart, void* ws, size_t ws_bytes,
+                                   sgs_stream_t stream);
+int sgs_edge_score_bwd_reduce_fused(const float* G, const float* opart, const uint32_t* dvbits, const float* dz, const float* w2, float p_drop,
+                                    int64_t N, int64_t H, int64_t nnz, const int32_t* in_ptr, const int32_t* in_eid, const int32_t* out_ptr,
+                                    float* out_codes, float* out_U, float* out_U_raw, sgs_stream_t stream);
 int sgs_edge_score_bwd_core_bits(const float* codes, const float* U, int64_t N, int64_t H, const int64_t* edge_index, int64_t E,
                                  int64_t edge_id_offset, const int64_t* active_eid, int64_t n_active, const float* grad_p, const float* W1,
                                  const float* b1, const float* w2, const float* b2, float p_drop, uint64_t seed, uint32_t site,
@@ -402,6 +422,11 @@ int sgs_endpoint_reduce_pair_bits(const float* dfeat, const uint32_t* dvbits, co
  * before the factor rowscale * scale (terms of d fc2.weight, sgs_edge_score_dw2_from_parts).  Tall-K shapes only (sgs_gemm_tn_mask_supported);
  * ws: sgs_gemm_tn_workspace_bytes(K, M, N). */
 int sgs_gemm_tn_mask_supported(int64_t K, int64_t M, int64_t N);
+/* ... with B never materialised: row k of B = codes[src k, :] * codes[dst k, :], (src, dst) = sd[k] (int32 [K, 2]), `codes` [*, N] row-major.
+ * Bit-identical to sgs_gemm_tn_mask on the materialised rows (same products, same order). */
+int sgs_gemm_tn_mask_gather(const uint32_t* Abits, const float* dz, const float* rowscale, float scale, const float* codes, const int32_t* sd,
+                            int64_t K, int64_t M, int64_t N, float* C, int64_t ldc, float* colsum_A, float* dz_sum, float* C_raw,
+                            float* colsum_raw, void* ws, size_t ws_bytes, sgs_stream_t stream);
 int sgs_gemm_tn_mask(const uint32_t* Abits, const float* dz, const float* rowscale, float scale, const float* B, int64_t K, int64_t M, int64_t N,
                      float* C, int64_t ldc, float* colsum_A, float* dz_sum, float* C_raw, float* colsum_raw, void* ws, size_t ws_bytes,
                      sgs_stream_t stream);

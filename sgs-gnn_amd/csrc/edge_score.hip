@@ -72,8 +72,10 @@ struct ScoreArgs {
     float* dz;               // backward: [n]
     float* feat;             // backward: [n,H]  x_s * x_d
     uint32_t* dvbits;        // backward (MODE 1), optional: [n, H/32] bit h of row r = [dropped hidden h of row r > 0] -- with dz and w2 that IS dv
-    const uint32_t* inbits;  // MODE 4 (dfeat from the mask): [n, H/32]
-    const float* indz;       // MODE 4: [n]
+    const uint32_t* inbits;  // MODE 4 / 5 (dfeat from the mask): [n, H/32]
+    const float* indz;       // MODE 4 / 5: [n]
+    const int32_t* sd;       // MODE 5: [n, 2] (src, dst) of every active row
+    float* opart;            // MODE 5: [cdiv(n, 32) + N, H] run-end partial sums of dfeat * codes[dst] (see the kernel)
 };
 
 // Workgroup = 64 edges x all HP = 32*NT hidden units; wave (eg, hh) owns edges 32eg..32eg+31 and
@@ -745,7 +747,7 @@ __global__ void __launch_bounds__(kT) pack_w1a_bf16x3(const float* __restrict__ 
 // set of accumulators: the same p as MODE 0, bit for bit, at ~0.6 x the time.
 template <int NT, int NW, int MODE = 0>
 __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(ScoreArgs a, const uint4* __restrict__ Wp16) {
-    constexpr bool BWD = MODE == 1, GEMMB = MODE == 4, GEMM = MODE == 2 || MODE == 4, PAIR = MODE == 3;
+    constexpr bool BWD = MODE == 1, FUSED = MODE == 5, GEMMB = MODE == 4 || MODE == 5, GEMM = MODE == 2 || GEMMB, PAIR = MODE == 3;
     constexpr int H = 32 * NT;
     constexpr int NPH = H / 16;              // phases: one 16-deep k-chunk each, one barrier per phase
     constexpr int CH = NT * 3 * 64;          // 16-byte words per k-chunk of W1a (all hidden units, three pieces)
@@ -882,6 +884,56 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
         chunk(wcur, fa, ph, pn);
         lstore(wnext);
         __syncthreads();
+    }
+    if constexpr (FUSED) {
+        // MODE 5: dfeat[r, :] = dz[r] * acc never reaches memory as such.  The two endpoint reductions of the scorer backward need
+        //   d codes[src r, :] += dfeat[r, :] * codes[dst r, :]      and      d codes[dst r, :] += dfeat[r, :] * codes[src r, :].
+        // The active rows are sorted by source (a drawn subset of a row-sorted edge list, in edge order), so the first sum runs over
+        // CONSECUTIVE rows: it is reduced here, per wave, as a segmented sum down the 32 rows of the tile (through LDS, one column per
+        // lane, fixed order) and only the RUN-END rows -- the last row of a source inside a wave -- write their partial sum, into slot
+        // (r >> 5) + src of `opart` (strictly increasing along the run ends, so no two collide; a node with b - a out-rows has
+        // ((b - 1) >> 5) - (a >> 5) + 1 of them, which the follow-up reduction adds in order).  The second sum gathers by destination:
+        // its rows G[r, :] = dfeat[r, :] * codes[src r, :] are written out (a.feat) and reduced by scorer_bwd_reduce.
+        // Against writing dfeat and reading it back twice: one [n, H] read and both codes gathers of the reduction are gone.
+        const float rs = live ? a.indz[r] : 0.f;
+        int sr = 0, dr = 0;
+        if (live) { sr = a.sd[2 * r]; dr = a.sd[2 * r + 1]; }
+        const int nxt = __shfl(sr, (lane & 32) | ((l31 + 1) & 31), 64);
+        const bool endrow = live && (l31 == 31 || r + 1 >= a.n || nxt != sr);
+        const uint32_t endmask = static_cast<uint32_t>(__ballot(endrow && kh == 0));      // bit = row of the tile (lanes 0..31)
+        constexpr int LS = 68;                                                           // padded row: 16-byte stores of 8 rows hit 32 distinct banks
+        // the W stages are dead (the loop ended on a barrier): at H = 256 they hold the four waves' tiles; at H = 128 they are too small
+        constexpr bool kInWl = sizeof(wl) >= static_cast<size_t>(NW) * 32 * LS * sizeof(float);
+        __shared__ float ot_own[kInWl ? 1 : NW * 32 * LS];
+        float* ot = (kInWl ? reinterpret_cast<float*>(&wl[0][0]) : ot_own) + wave * (32 * LS);
+        const float* cs = a.codes + static_cast<int64_t>(sr) * H + 4 * kh;
+        const float* cd = a.codes + static_cast<int64_t>(dr) * H + 4 * kh;
+        const int64_t wrow = (row0 + 32 * wave) >> 5;                                    // this wave's index among all 32-row tiles
+#pragma unroll
+        for (int Q = 0; Q < NT / 2; ++Q) {                                               // 64 columns at a time
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii) {
+                const int i = 8 * Q + ii, t = i >> 2, g4 = i & 3;
+                const float4 s4 = *reinterpret_cast<const float4*>(cs + 8 * i);
+                const float4 d4 = *reinterpret_cast<const float4*>(cd + 8 * i);
+                const float f0 = rs * acc[t][4 * g4], f1 = rs * acc[t][4 * g4 + 1], f2 = rs * acc[t][4 * g4 + 2], f3 = rs * acc[t][4 * g4 + 3];
+                if (live) *reinterpret_cast<float4*>(a.feat + r * H + 8 * i + 4 * kh) = make_float4(f0 * s4.x, f1 * s4.y, f2 * s4.z, f3 * s4.w);
+                *reinterpret_cast<float4*>(ot + l31 * LS + 8 * ii + 4 * kh) = make_float4(f0 * d4.x, f1 * d4.y, f2 * d4.z, f3 * d4.w);
+            }
+            __syncthreads();
+            float run = 0.f;
+#pragma unroll
+            for (int row = 0; row < 32; ++row) {
+                run += ot[row * LS + lane];
+                if ((endmask >> row) & 1u) {                                             // (wave-uniform)
+                    const int64_t slot = wrow + __builtin_amdgcn_readlane(sr, row);
+                    a.opart[slot * H + 64 * Q + lane] = run;
+                    run = 0.f;
+                }
+            }
+            __syncthreads();
+        }
+        return;
     }
     if constexpr (GEMM) {                            // out[r, 8 i + 4 kh + j] = accumulator register 4 g4 + j of tile t (i = 4 t + g4)
         if (live) {
@@ -1318,7 +1370,7 @@ __global__ void __launch_bounds__(kT) scorer_bwd_prep(const float* __restrict__ 
                                                      const int64_t* __restrict__ dst, const int64_t* __restrict__ active, int64_t n,
                                                      const float* __restrict__ gp, const float* __restrict__ p,
                                                      const uint32_t* __restrict__ maskbits, float* __restrict__ dz,
-                                                     uint32_t* __restrict__ bits, float* __restrict__ feat) {
+                                                     uint32_t* __restrict__ bits, float* __restrict__ feat, int32_t* __restrict__ sd) {
     constexpr int R = 4;                                                  // rows per wave: their index chains and gathers in flight together
     const int lane = threadIdx.x & 63;
     const int64_t r0 = ((static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6) * R;
@@ -1337,7 +1389,9 @@ __global__ void __launch_bounds__(kT) scorer_bwd_prep(const float* __restrict__ 
         if (r0 + u >= n) break;
         if (lane < wpr) bits[(r0 + u) * wpr + lane] = maskbits[e[u] * wpr + lane];
         if (lane == 63) { const float pe = p[e[u]]; dz[r0 + u] = gp[r0 + u] * pe * (1.0f - pe); }
+        if (sd && lane == 62) { sd[2 * (r0 + u)] = static_cast<int32_t>(s[u]); sd[2 * (r0 + u) + 1] = static_cast<int32_t>(d[u]); }
     }
+    if (!feat) return;                                                    // the fused backward gathers the rows where it needs them
     for (int64_t c0 = static_cast<int64_t>(lane) * 4; c0 < H; c0 += 256) {
         float4 a[R], b[R];
 #pragma unroll
@@ -1455,6 +1509,116 @@ __global__ void __launch_bounds__(64 * NW) endpoint_reduce_pair_rowblock(const f
                 for (int g = 0; g < NW; g += 4) sum += (part[which][g][c] + part[which][g + 1][c]) + (part[which][g + 2][c] + part[which][g + 3][c]);
                 if (BITS && which) {
                     if (out_Uraw) out_Uraw[v * H + cbase + c] = sum;      // before the column factor: a term of d fc2.weight (scorer_dw2_from_parts)
+                    sum *= w2[cbase + c] * scale;
+                }
+                (which ? out_U : out_codes)[v * H + cbase + c] = sum;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// The endpoint reductions of the FUSED scorer backward (after MODE 5 of the bf16x6 loop), one workgroup per node v:
+//   out_codes[v, :] = sum over v's run-end slots of opart  (the by-source half, already reduced per 32-row tile)
+//                   + sum_{k in in-row v} G[in_eid[k], :]  (the by-destination half: G = dfeat * codes[src])
+//   R[v, :]         = sum_{k in out-row v} dz[e] bit[e, :] - sum_{k in in-row v} dz[e] bit[e, :];   out_U = R * w2 * scale, out_Uraw = R
+// Needs the active rows sorted by source: out-row v is then the rows out_ptr[v] .. out_ptr[v + 1] - 1 themselves.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) scorer_bwd_reduce(const float* __restrict__ G, const float* __restrict__ opart,
+                                                            const uint32_t* __restrict__ bits, const float* __restrict__ dz,
+                                                            const float* __restrict__ w2, float scale, int64_t N, int64_t H,
+                                                            const int* __restrict__ in_ptr, const int* __restrict__ in_eid,
+                                                            const int* __restrict__ out_ptr, float* __restrict__ out_codes,
+                                                            float* __restrict__ out_U, float* __restrict__ out_Uraw) {
+    __shared__ float part[2][NW][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t v = blockIdx.x;
+    const int ob = out_ptr[v], no = out_ptr[v + 1] - ob;
+    const int ib = in_ptr[v], ni = in_ptr[v + 1] - ib;
+    const int w0 = ob >> 5, np = no > 0 ? ((ob + no - 1) >> 5) - w0 + 1 : 0;          // run-end slots of this node: tiles w0 .. w0 + np - 1
+    const int wpr = static_cast<int>(H >> 5);
+    for (int64_t cbase = 0; cbase < H; cbase += 256) {
+        const int64_t c0 = cbase + static_cast<int64_t>(lane) * 4;
+        float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c0 < H) {
+            const int wsel = static_cast<int>(c0 >> 5), wsh = static_cast<int>(c0 & 31);
+            // (1) in-row: G rows + mask bits (sign -).  kEpU entries in flight per wave, every load unconditional (entries past the row
+            //     are clamped to its last entry and weighted 0)
+            for (int k0 = wave; k0 < ni; k0 += kEpU * NW) {
+                int er[kEpU];
+                float ok[kEpU];
+#pragma unroll
+                for (int u = 0; u < kEpU; ++u) {
+                    const int k = k0 + NW * u;
+                    er[u] = in_eid[ib + (k < ni ? k : ni - 1)];
+                    ok[u] = k < ni ? 1.f : 0.f;
+                }
+                float4 m1[kEpU];
+                uint32_t wd[kEpU];
+                float dzr[kEpU];
+#pragma unroll
+                for (int u = 0; u < kEpU; ++u) {
+                    m1[u] = *reinterpret_cast<const float4*>(G + static_cast<int64_t>(er[u]) * H + c0);
+                    wd[u] = bits[static_cast<int64_t>(er[u]) * wpr + wsel];
+                    dzr[u] = dz[er[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < kEpU; ++u) {
+                    const uint32_t w = wd[u] >> wsh;
+                    const float dd = ok[u] * dzr[u];
+                    a1[0] = fmaf(ok[u], m1[u].x, a1[0]); a1[1] = fmaf(ok[u], m1[u].y, a1[1]);
+                    a1[2] = fmaf(ok[u], m1[u].z, a1[2]); a1[3] = fmaf(ok[u], m1[u].w, a1[3]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a2[j] -= (w >> j) & 1u ? dd : 0.f;
+                }
+            }
+            // (2) out-row: mask bits only (sign +); the rows themselves are ob .. ob + no - 1
+            for (int k0 = wave; k0 < no; k0 += kEpU * NW) {
+                uint32_t wd[kEpU];
+                float dzr[kEpU];
+#pragma unroll
+                for (int u = 0; u < kEpU; ++u) {
+                    const int k = k0 + NW * u;
+                    const int64_t e = ob + (k < no ? k : no - 1);
+                    wd[u] = bits[e * wpr + wsel];
+                    dzr[u] = dz[e] * (k < no ? 1.f : 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < kEpU; ++u) {
+                    const uint32_t w = wd[u] >> wsh;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a2[j] += (w >> j) & 1u ? dzr[u] : 0.f;
+                }
+            }
+            // (3) the by-source half: this node's run-end partial sums, tile after tile
+            for (int k0 = wave; k0 < np; k0 += kEpU * NW) {
+                float4 m1[kEpU];
+                float ok[kEpU];
+#pragma unroll
+                for (int u = 0; u < kEpU; ++u) {
+                    const int k = k0 + NW * u;
+                    const int64_t slot = static_cast<int64_t>(w0 + (k < np ? k : np - 1)) + v;
+                    m1[u] = *reinterpret_cast<const float4*>(opart + slot * H + c0);
+                    ok[u] = k < np ? 1.f : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < kEpU; ++u) {
+                    a1[0] = fmaf(ok[u], m1[u].x, a1[0]); a1[1] = fmaf(ok[u], m1[u].y, a1[1]);
+                    a1[2] = fmaf(ok[u], m1[u].z, a1[2]); a1[3] = fmaf(ok[u], m1[u].w, a1[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { part[0][wave][lane * 4 + j] = a1[j]; part[1][wave][lane * 4 + j] = a2[j]; }
+        __syncthreads();
+        for (int tt = threadIdx.x; tt < 512; tt += 64 * NW) {
+            const int which = tt >> 8, c = tt & 255;
+            if (cbase + c < H) {
+                float sum = 0.f;
+#pragma unroll
+                for (int g = 0; g < NW; g += 4) sum += (part[which][g][c] + part[which][g + 1][c]) + (part[which][g + 2][c] + part[which][g + 3][c]);
+                if (which) {
+                    if (out_Uraw) out_Uraw[v * H + cbase + c] = sum;
                     sum *= w2[cbase + c] * scale;
                 }
                 (which ? out_U : out_codes)[v * H + cbase + c] = sum;
@@ -1913,16 +2077,85 @@ int sgs_endpoint_reduce_pair(const float* dfeat, const float* dv, const float* c
     return SGS_OK;
 }
 
-int sgs_edge_score_bwd_prep(const float* codes, int64_t N, int64_t H, const int64_t* edge_index, int64_t E, const int64_t* active_eid,
-                            int64_t n_active, const float* grad_p, const float* p, const uint32_t* maskbits, float* dz, uint32_t* dvbits,
-                            float* feat, sgs_stream_t stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+static int bwd_prep_impl(const float* codes, int64_t N, int64_t H, const int64_t* edge_index, int64_t E, const int64_t* active_eid,
+                         int64_t n_active, const float* grad_p, const float* p, const uint32_t* maskbits, float* dz, uint32_t* dvbits,
+                         float* feat, int32_t* sd, hipStream_t stream) {
     SGS_REQUIRE(N > 0 && H > 0 && H % 32 == 0 && E >= 0 && n_active >= 0 && (active_eid || n_active == E), SGS_EINVAL,
                 "sgs_edge_score_bwd_prep: bad arguments (H %% 32 == 0; n_active == E when active_eid is NULL)");
     if (n_active == 0) return SGS_OK;
-    SGS_REQUIRE(codes && edge_index && grad_p && p && maskbits && dz && dvbits && feat, SGS_EINVAL, "sgs_edge_score_bwd_prep: null pointer");
+    SGS_REQUIRE(codes && edge_index && grad_p && p && maskbits && dz && dvbits && (feat || sd), SGS_EINVAL, "sgs_edge_score_bwd_prep: null pointer");
     hipLaunchKernelGGL(scorer_bwd_prep, dim3(static_cast<unsigned>(cdiv(cdiv(n_active, 4) * 64, kT))), dim3(kT), 0, stream, codes, H, edge_index,
-                       edge_index + E, active_eid, n_active, grad_p, p, maskbits, dz, dvbits, feat);
+                       edge_index + E, active_eid, n_active, grad_p, p, maskbits, dz, dvbits, feat, sd);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_edge_score_bwd_prep(const float* codes, int64_t N, int64_t H, const int64_t* edge_index, int64_t E, const int64_t* active_eid,
+                            int64_t n_active, const float* grad_p, const float* p, const uint32_t* maskbits, float* dz, uint32_t* dvbits,
+                            float* feat, sgs_stream_t stream_) {
+    SGS_REQUIRE(feat || n_active == 0, SGS_EINVAL, "sgs_edge_score_bwd_prep: null pointer");
+    return bwd_prep_impl(codes, N, H, edge_index, E, active_eid, n_active, grad_p, p, maskbits, dz, dvbits, feat, nullptr,
+                         static_cast<hipStream_t>(stream_));
+}
+
+/* The same pass for the FUSED backward: no feat (its consumers gather the code rows themselves); the endpoints of every active row
+ * as int32 pairs instead (sd [n, 2]). */
+int sgs_edge_score_bwd_prep_sd(const float* codes, int64_t N, int64_t H, const int64_t* edge_index, int64_t E, const int64_t* active_eid,
+                               int64_t n_active, const float* grad_p, const float* p, const uint32_t* maskbits, float* dz, uint32_t* dvbits,
+                               int32_t* sd, sgs_stream_t stream_) {
+    SGS_REQUIRE(sd || n_active == 0, SGS_EINVAL, "sgs_edge_score_bwd_prep_sd: null pointer");
+    return bwd_prep_impl(codes, N, H, edge_index, E, active_eid, n_active, grad_p, p, maskbits, dz, dvbits, nullptr, sd,
+                         static_cast<hipStream_t>(stream_));
+}
+
+/* MODE 5 of the bf16x6 loop (see the kernel): G [n, H] = dfeat * codes[src], opart [cdiv(n, 32) + N, H] = run-end partial sums of
+ * dfeat * codes[dst].  The active rows must be sorted by source. */
+size_t sgs_edge_score_bwd_fused_opart_rows(int64_t n, int64_t N) { return static_cast<size_t>(cdiv(n < 0 ? 0 : n, 32) + (N < 0 ? 0 : N)); }
+
+int sgs_edge_score_bwd_dfeat_fused(const uint32_t* dvbits, const float* dz, const int32_t* sd, const float* codes, int64_t n, int64_t N, int64_t H,
+                                   const float* W1, const float* w2, float p_drop, float* G, float* opart, void* ws, size_t ws_bytes,
+                                   sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(n >= 0 && N > 0 && H > 0 && p_drop >= 0.f && p_drop < 1.f, SGS_EINVAL, "sgs_edge_score_bwd_dfeat_fused: bad arguments");
+    SGS_REQUIRE(sgs_edge_score_bwd_bits_supported(H), SGS_EINVAL, "sgs_edge_score_bwd_dfeat_fused: H=%lld unsupported (128 or 256)", (long long)H);
+    if (n == 0) return SGS_OK;
+    SGS_REQUIRE(dvbits && dz && sd && codes && W1 && w2 && G && opart, SGS_EINVAL, "sgs_edge_score_bwd_dfeat_fused: null pointer");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_workspace_bytes(0, H, 0), SGS_EWORKSPACE, "sgs_edge_score_bwd_dfeat_fused: workspace too small");
+    Carver cv(ws);
+    cv.take<float>(static_cast<size_t>(H) * H);
+    cv.take<float>(0);
+    cv.take<float>(0);
+    cv.take<unsigned int>(64);
+    uint4* Wp16 = cv.take<uint4>(static_cast<size_t>(H) * H * 6 / 16);
+    hipLaunchKernelGGL(pack_w1a_bf16x3<true>, dim3(static_cast<unsigned>(cdiv((H / 16) * (H / 32) * 64, kT))), dim3(kT), 0, stream, W1,
+                       static_cast<int>(H), Wp16, w2, 1.0f / (1.0f - p_drop));
+    ScoreArgs a{};
+    a.inbits = dvbits; a.indz = dz; a.n = n; a.H = static_cast<int>(H); a.feat = G; a.codes = codes; a.sd = sd; a.opart = opart;
+    const dim3 grid(static_cast<unsigned>(cdiv(n, 128))), blk(256);
+    if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4, 5>), grid, blk, 0, stream, a, Wp16);
+    else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4, 5>), grid, blk, 0, stream, a, Wp16);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+/* The reductions that follow it: out_codes, out_U (and out_U_raw, optional) as sgs_endpoint_reduce_pair_bits produces them. */
+int sgs_edge_score_bwd_reduce_fused(const float* G, const float* opart, const uint32_t* dvbits, const float* dz, const float* w2, float p_drop,
+                                    int64_t N, int64_t H, int64_t nnz, const int32_t* in_ptr, const int32_t* in_eid, const int32_t* out_ptr,
+                                    float* out_codes, float* out_U, float* out_U_raw, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && H >= 0 && H % 32 == 0 && N < (int64_t(1) << 31) && p_drop >= 0.f && p_drop < 1.f, SGS_EINVAL,
+                "sgs_edge_score_bwd_reduce_fused: needs H %% 32 == 0");
+    if (N == 0 || H == 0) return SGS_OK;
+    SGS_REQUIRE(G && opart && dvbits && dz && w2 && in_ptr && in_eid && out_ptr && out_codes && out_U, SGS_EINVAL,
+                "sgs_edge_score_bwd_reduce_fused: null pointer");
+    const dim3 grid(static_cast<unsigned>(N));
+    const float scale = 1.0f / (1.0f - p_drop);
+    if (nnz >= 64 * N)
+        hipLaunchKernelGGL((scorer_bwd_reduce<16>), grid, dim3(1024), 0, stream, G, opart, dvbits, dz, w2, scale, N, H, in_ptr, in_eid, out_ptr,
+                           out_codes, out_U, out_U_raw);
+    else
+        hipLaunchKernelGGL((scorer_bwd_reduce<4>), grid, dim3(256), 0, stream, G, opart, dvbits, dz, w2, scale, N, H, in_ptr, in_eid, out_ptr,
+                           out_codes, out_U, out_U_raw);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

@@ -231,11 +231,17 @@ __global__ void __launch_bounds__(64) gemm_tn_tall_tile(const float* __restrict_
 // MASK: A is a 0 / 1 matrix given as bits (Abits [K, M/32], bit m of row k) times a per-row factor dz[k]: the scorer's
 // dv = diag(dz) mask diag(w2 / (1 - p)).  The mask is ONE exact bf16 piece and dz moves to the B side (b <- dz[k] * b before the split), so
 // a product is 3 MFMAs instead of 6 and the A stream is 1/32 of the bytes; the column factor w2 / (1 - p) is applied by gemm_tn_reduce.
-template <int NW, bool MASK = false>
+// GATHER (with MASK): B is never materialised -- row k of B is codes[src k, :] * codes[dst k, :] with (src, dst) = sd[k] (the scorer's
+// feat = x_s * x_d; `B` is then the codes table [*, N]).  The endpoints of a step are fetched one step before its rows (a dependent
+// gather needs its index first), the rows two steps before their products -- same values, same order of operations as reading a
+// materialised feat, so C is bit-identical; what goes away is the [K, N] array's round trip through HBM (written by the prep pass,
+// read once per 128-row M-tile here).
+template <int NW, bool MASK = false, bool GATHER = false>
 __global__ void __launch_bounds__(64 * NW) gemm_tn_tall_bf16x6(const float* __restrict__ A, const float* __restrict__ B, int64_t K, int M, int N,
                                                               int ksplit, float* __restrict__ slab, float* __restrict__ cpart,
                                                               const uint32_t* __restrict__ Abits = nullptr, const float* __restrict__ dz = nullptr,
-                                                              float* __restrict__ dzpart = nullptr) {
+                                                              float* __restrict__ dzpart = nullptr, const int32_t* __restrict__ sd = nullptr) {
+    static_assert(!GATHER || MASK, "the gathered B operand comes with the mask form of A");
     extern __shared__ float red_lds[];       // NW > 1: [NW / 2][8 tiles x 16 registers][64 lanes] partial tiles + [NW / 2][4][64] column sums
     const int lane = threadIdx.x & 63, g = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform, and the compiler should know: slice bounds in SGPRs
@@ -257,7 +263,8 @@ __global__ void __launch_bounds__(64 * NW) gemm_tn_tall_bf16x6(const float* __re
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
     const bool want_dz = MASK && dzpart != nullptr && blockIdx.x == 0 && blockIdx.y == 0;      // the slice's sum of dz (d fc2.bias) on the way
     float dzs = 0.f;
-    struct Raw { float4 a[8]; float2 b[8]; uint32_t aw[8]; float dzr[8]; int64_t k; };      // (a | aw, dzr: the unused ones are never live)
+    struct Raw { float4 a[8]; float2 b[8]; float2 b2[8]; uint32_t aw[8]; float dzr[8]; int64_t k; };      // (a | aw, dzr, b2: the unused ones are never live)
+    struct Idx { int2 e[8]; };                                              // GATHER: the endpoints of one step's eight rows
     const int wsel = ia >> 5, wsh = ia & 31;
     // MASK: per-lane bases of the slice, so that a step's 24 loads are base + (row-in-slice) * stride in 32-bit arithmetic (64-bit index
     // math per load made this loop VALU-bound: ~620 vector instructions per 24 MFMAs, measured 92 us; the matrix work is 16 us)
@@ -265,7 +272,25 @@ __global__ void __launch_bounds__(64 * NW) gemm_tn_tall_bf16x6(const float* __re
     const int lim = static_cast<int>(k1 - k0);                              // rows in this slice (<= 0: an empty trailing slice)
     const uint32_t* Ab = MASK ? Abits + k0 * wpr + wsel : nullptr;
     const float* Db = MASK ? dz + k0 : nullptr;
-    const float* Bb = B + k0 * N + jb;
+    const float* Bb = GATHER ? B + jb : B + k0 * N + jb;
+    const int2* Sb = GATHER ? reinterpret_cast<const int2*>(sd) + k0 : nullptr;
+    auto load_idx = [&](int64_t k, Idx& ix) {                               // (rows past the slice: its last row, neutralised through dz = 0)
+        const int rel = static_cast<int>(k - k0) + 8 * g;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ix.e[j] = Sb[max(min(rel + j, lim - 1), 0)];
+    };
+    auto load_rows = [&](int64_t k, Raw& r, const Idx& ix) {
+        r.k = k;
+        const int rel = static_cast<int>(k - k0) + 8 * g;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int rc = max(min(rel + j, lim - 1), 0);
+            r.aw[j] = Ab[rc * wpr];
+            r.dzr[j] = Db[rc];
+            r.b[j] = *reinterpret_cast<const float2*>(Bb + static_cast<int64_t>(ix.e[j].x) * N);
+            r.b2[j] = *reinterpret_cast<const float2*>(Bb + static_cast<int64_t>(ix.e[j].y) * N);
+        }
+    };
     auto load = [&](int64_t k, Raw& r) {
         r.k = k;
         if constexpr (MASK) {
@@ -304,6 +329,10 @@ __global__ void __launch_bounds__(64 * NW) gemm_tn_tall_bf16x6(const float* __re
     };
     auto mma = [&](const Raw& r_) {
         Raw r = r_;
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { r.b[j].x *= r.b2[j].x; r.b[j].y *= r.b2[j].y; }      // feat = x_s * x_d, rounded once as the stored array was
+        }
         if constexpr (MASK) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) r.aw[j] >>= wsh;            // bits of columns ia .. ia + 3 in the low nibble
@@ -384,8 +413,35 @@ __global__ void __launch_bounds__(64 * NW) gemm_tn_tall_bf16x6(const float* __re
         }
     };
     Raw r0, r1;
-    if (!MASK || lim > 0) load(k0, r0);
-    if constexpr (MASK) {
+    if constexpr (GATHER) {
+        if (lim > 0) {
+            // step n multiplies stage n % 3 while the rows of step n + 2 and the endpoints of step n + 3 are in flight
+            Raw r2;
+            Idx ix;
+            load_idx(k0, ix);
+            load_rows(k0, r0, ix);
+            load_idx(k0 + 16, ix);
+            load_rows(k0 + 16, r1, ix);
+            load_idx(k0 + 32, ix);
+#pragma unroll 1
+            for (int64_t k = k0; k < k1; k += 48) {
+                load_rows(k + 32, r2, ix);
+                load_idx(k + 48, ix);
+                mma(r0);
+                load_rows(k + 48, r0, ix);
+                load_idx(k + 64, ix);
+                mma(r1);
+                load_rows(k + 64, r1, ix);
+                load_idx(k + 80, ix);
+                mma(r2);
+            }
+        }
+    } else if constexpr (!MASK) {
+        load(k0, r0);
+    } else {
+        if (lim > 0) load(k0, r0);
+    }
+    if constexpr (MASK && !GATHER) {
         if (lim > 0) {
         // a stage is 32 registers here (against 48), so THREE are kept: two steps of loads in flight behind the one being multiplied --
         // with one wave per SIMD the loop runs at the memory latency per step, and the second stage in flight halves it (measured)
@@ -401,7 +457,7 @@ __global__ void __launch_bounds__(64 * NW) gemm_tn_tall_bf16x6(const float* __re
             mma(r2);
         }
         }
-    } else {
+    } else if constexpr (!MASK) {
 #pragma unroll 1
         for (int64_t k = k0; k < k1; k += 32) {
             load(k + 16, r1);                                   // rows past k1 load zeros
@@ -497,7 +553,7 @@ size_t sgs_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N) {
 static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, float* colsum_A, void* ws,
                         size_t ws_bytes, hipStream_t stream, int64_t ldc = 0, const uint32_t* Abits = nullptr, const float* dz = nullptr,
                         const float* rowscale = nullptr, float scale = 1.f, float* dz_sum = nullptr, float* C_raw = nullptr,
-                        float* colsum_raw = nullptr);
+                        float* colsum_raw = nullptr, const int32_t* sd = nullptr);
 // tall-K shapes: 1 = bf16x6 kernel (default; measured 147 vs 175 us incl. the 34 us slab reduction at K = 100 000, M = N = 256: the
 // operand splits, 264 vector instructions per 48 MFMAs, are at the budget the matrix pipe leaves), 0 = fp32-MFMA kernel
 static int g_tall_bf16x6 = 1;
@@ -544,9 +600,22 @@ int sgs_gemm_tn_mask(const uint32_t* Abits, const float* dz, const float* rowsca
                         C_raw, colsum_raw);
 }
 
+/* The same product with B = codes[src] * codes[dst] gathered per row (sd [K, 2] int32 endpoints; `codes` [*, N]): the scorer's weight
+ * gradient without a materialised feat.  Bit-identical to sgs_gemm_tn_mask on the materialised rows. */
+int sgs_gemm_tn_mask_gather(const uint32_t* Abits, const float* dz, const float* rowscale, float scale, const float* codes, const int32_t* sd,
+                            int64_t K, int64_t M, int64_t N, float* C, int64_t ldc, float* colsum_A, float* dz_sum, float* C_raw,
+                            float* colsum_raw, void* ws, size_t ws_bytes, sgs_stream_t stream_) {
+    SGS_REQUIRE(ldc >= N, SGS_EINVAL, "sgs_gemm_tn_mask_gather: ldc < N");
+    SGS_REQUIRE(Abits && dz && rowscale && codes && sd, SGS_EINVAL, "sgs_gemm_tn_mask_gather: null pointer");
+    SGS_REQUIRE(sgs_gemm_tn_mask_supported(K, M, N), SGS_EINVAL, "sgs_gemm_tn_mask_gather: shape not served (check sgs_gemm_tn_mask_supported)");
+    SGS_REQUIRE(!colsum_raw || colsum_A, SGS_EINVAL, "sgs_gemm_tn_mask_gather: colsum_raw needs colsum_A");
+    return gemm_tn_impl(nullptr, codes, K, M, N, C, colsum_A, ws, ws_bytes, static_cast<hipStream_t>(stream_), ldc, Abits, dz, rowscale, scale,
+                        dz_sum, C_raw, colsum_raw, sd);
+}
+
 static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, float* colsum_A, void* ws,
                         size_t ws_bytes, hipStream_t stream, int64_t ldc, const uint32_t* Abits, const float* dz, const float* rowscale,
-                        float scale, float* dz_sum, float* C_raw, float* colsum_raw) {
+                        float scale, float* dz_sum, float* C_raw, float* colsum_raw, const int32_t* sd) {
     SGS_REQUIRE(K >= 0 && M >= 0 && N >= 0 && M < (1 << 30) && N < (1 << 30), SGS_EINVAL, "sgs_gemm_tn: bad sizes");
     if (M == 0 || N == 0) return SGS_OK;
     SGS_REQUIRE(C && (K == 0 || ((A || Abits) && B)), SGS_EINVAL, "sgs_gemm_tn: null pointer");
@@ -570,6 +639,17 @@ static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, in
         n_slabs = ks / NW;
         // cpart holds ks * M floats and the NW-wave workgroups fill n_slabs * M of them: the K-slices' dz sums go behind those
         float* dzpart = dz_sum ? cpart + static_cast<size_t>(n_slabs) * M : nullptr;
+        if (sd) {
+            static bool raised_g = false;
+            if (!raised_g) {
+                SGS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_tall_bf16x6<NW, true, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+                raised_g = true;
+            }
+            hipLaunchKernelGGL((gemm_tn_tall_bf16x6<NW, true, true>), dim3(cdiv(M, 128), cdiv(N, 64), n_slabs), dim3(64 * NW), lds, stream, A, B, K,
+                               static_cast<int>(M), static_cast<int>(N), ks, slab, (colsum_A || dz_sum) ? cpart : static_cast<float*>(nullptr), Abits,
+                               dz, dzpart, sd);
+        } else
         hipLaunchKernelGGL((gemm_tn_tall_bf16x6<NW, true>), dim3(cdiv(M, 128), cdiv(N, 64), n_slabs), dim3(64 * NW), lds, stream, A, B, K,
                            static_cast<int>(M), static_cast<int>(N), ks, slab, (colsum_A || dz_sum) ? cpart : static_cast<float*>(nullptr), Abits, dz,
                            dzpart);

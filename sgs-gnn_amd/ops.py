@@ -608,6 +608,25 @@ def _endpoint_reduce(M_out, M_in, T, graph: Graph, s_out, s_in, H):
 
 _mask_backward = True        # False: the dense fp32 dv path at every size (tests compare the two)
 _fwd_mask = True             # False: the forward keeps no mask; the backward recomputes the hidden layer (sgs_edge_score_bwd_core_bits)
+_fused_backward = True       # False: feat / dfeat as [n, H] arrays and sgs_endpoint_reduce_pair_bits (the form for edge lists not sorted by source)
+
+
+def src_sorted(edge_index: torch.Tensor) -> bool:
+    """Is the edge list sorted by source (PyG's coalesced / row-sorted layout: every loader of the reference emits it)?  Cached on the
+    tensor like its Graph; computing it reads one word back, so it is never computed inside a stream capture (unknown = False there:
+    the unfused backward is correct for any order).  stepgraph.py stamps its static slot tensors after checking the partitions."""
+    c = getattr(edge_index, "_sgs_src_sorted", None)
+    if c is not None and c[1] == edge_index._version:
+        return c[0]
+    if torch.cuda.is_current_stream_capturing():
+        return False
+    n = edge_index.shape[1]
+    ok = True if n < 2 else bool((edge_index[0, 1:] >= edge_index[0, :-1]).all())
+    try:
+        edge_index._sgs_src_sorted = (ok, edge_index._version)
+    except Exception:
+        pass
+    return ok
 
 
 class _EdgeScore(torch.autograd.Function):
@@ -647,6 +666,8 @@ class _EdgeScore(torch.autograd.Function):
                                             ws.data_ptr(), ws.numel(), _stream()), "sgs_edge_score_fwd")
         ctx.save_for_backward(codes, U, W1, b1, w2, b2, edge_index, *((maskbits, out) if maskbits is not None else ()))
         ctx.active, ctx.p, ctx.seed, ctx.site, ctx.offset = active, float(p), seed, site, edge_id_offset
+        # the fused backward needs the active rows grouped by source: true for a drawn subset (ascending ids) of a row-sorted list
+        ctx.src_sorted = maskbits is not None and _fused_backward and src_sorted(edge_index)
         return out
 
     @staticmethod
@@ -747,8 +768,10 @@ def _edge_score_backward_mask(ctx, L, codes, U, W1, b1, w2, b2, edge_index, eid,
     f32 = dict(dtype=torch.float32, device=dev)
     p = ctx.p
     bits = torch.empty(n, H // 32, dtype=torch.int32, device=dev)
-    feat = torch.empty(n, H, **f32)
     dz = torch.empty(n, **f32)
+    if kept and eid is not None and getattr(ctx, "src_sorted", False) and _fused_backward:
+        return _edge_score_backward_fused(ctx, L, codes, U, W1, b1, w2, edge_index, eid, graph, n, gp_act, kept, bits, dz)
+    feat = torch.empty(n, H, **f32)
     hdz = Traw = craw = Rraw = None
     if kept:
         # the forward kept the mask and p: no recompute -- dz, the active rows' mask and feat in one pass; d fc2.weight from the consumers' parts
@@ -784,6 +807,41 @@ def _edge_score_backward_mask(ctx, L, codes, U, W1, b1, w2, b2, edge_index, eid,
         dw2 = torch.empty(H, **f32)
         _lib.check(L.sgs_edge_score_dw2_from_parts(_ptr(W1), _ptr(Traw), _ptr(U), _ptr(Rraw), _ptr(b1), _ptr(craw), N, H, p, _ptr(dw2), _stream()),
                    "sgs_edge_score_dw2_from_parts")
+    return _edge_score_backward_mask_tail(L, codes, W1, dcodes, dU, dW1, db1, dw2, db2)
+
+
+def _edge_score_backward_fused(ctx, L, codes, U, W1, b1, w2, edge_index, eid, graph, n, gp_act, kept, bits, dz):
+    """The no-recompute backward with neither feat nor dfeat as [n, H] arrays (include/sgs_hip.h, "FUSED form"): the active rows are sorted
+    by source, so the by-source half of d codes is reduced inside the dfeat contraction's epilogue, and the weight-gradient GEMM gathers
+    x_s * x_d itself.  Four launches (+ the W1a pack): prep (dz, mask rows, endpoints), dfeat + by-source sums, d W1a, the reductions."""
+    N, H = codes.shape
+    E = edge_index.shape[1]
+    dev = codes.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    p = ctx.p
+    maskbits, p_out = kept
+    sd = torch.empty(n, 2, dtype=torch.int32, device=dev)
+    _lib.check(L.sgs_edge_score_bwd_prep_sd(_ptr(codes), N, H, _ptr(edge_index), E, _ptr(eid), n, _ptr(gp_act), _ptr(p_out), _ptr(maskbits),
+                                            _ptr(dz), _ptr(bits), _ptr(sd), _stream()), "sgs_edge_score_bwd_prep_sd")
+    G = torch.empty(n, H, **f32)
+    opart = torch.empty(L.sgs_edge_score_bwd_fused_opart_rows(n, N), H, **f32)
+    wsd = workspace(L.sgs_edge_score_workspace_bytes(0, H, 0), dev)
+    _lib.check(L.sgs_edge_score_bwd_dfeat_fused(_ptr(bits), _ptr(dz), _ptr(sd), _ptr(codes), n, N, H, _ptr(W1), _ptr(w2), p, _ptr(G), _ptr(opart),
+                                                wsd.data_ptr(), wsd.numel(), _stream()), "sgs_edge_score_bwd_dfeat_fused")
+    dW1 = torch.empty_like(W1)
+    db1, db2 = torch.empty(H, **f32), torch.empty(1, **f32)
+    Traw, craw, Rraw = torch.empty(H, H, **f32), torch.empty(H, **f32), torch.empty(N, H, **f32)
+    scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+    wsg = workspace(L.sgs_gemm_tn_workspace_bytes(n, H, H), dev)
+    _lib.check(L.sgs_gemm_tn_mask_gather(_ptr(bits), _ptr(dz), _ptr(w2), scale, _ptr(codes), _ptr(sd), n, H, H, _ptr(dW1), 2 * H, _ptr(db1), _ptr(db2),
+                                         _ptr(Traw), _ptr(craw), wsg.data_ptr(), wsg.numel(), _stream()), "sgs_gemm_tn_mask_gather")
+    dcodes, dU = torch.empty(N, H, **f32), torch.empty(N, H, **f32)
+    _lib.check(L.sgs_edge_score_bwd_reduce_fused(_ptr(G), _ptr(opart), _ptr(bits), _ptr(dz), _ptr(w2), p, N, H, graph.n_edges, _ptr(graph.in_ptr),
+                                                 _ptr(graph.in_eid), _ptr(graph.out_ptr), _ptr(dcodes), _ptr(dU), _ptr(Rraw), _stream()),
+               "sgs_edge_score_bwd_reduce_fused")
+    dw2 = torch.empty(H, **f32)
+    _lib.check(L.sgs_edge_score_dw2_from_parts(_ptr(W1), _ptr(Traw), _ptr(U), _ptr(Rraw), _ptr(b1), _ptr(craw), N, H, p, _ptr(dw2), _stream()),
+               "sgs_edge_score_dw2_from_parts")
     return _edge_score_backward_mask_tail(L, codes, W1, dcodes, dU, dW1, db1, dw2, db2)
 
 

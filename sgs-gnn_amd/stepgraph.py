@@ -190,6 +190,9 @@ class StepGraphs:
         self.pairs_ok = fc1 is not None and bool(_lib.lib().sgs_edge_score_paired_supported(int(fc1.weight.shape[0])))
         self.nfeat = None
         self.stage_cache = {}                           # (batch key, slot id) -> (descriptor array, n segments, dims array, keep-alive)
+        # the fused scorer backward (ops._edge_score_backward_fused) needs edge lists sorted by source; a capture bakes the choice in, so
+        # the slots' static edge_index carries the flag and a partition that is not sorted drops the captures made under it (forward())
+        self.src_sorted = True
         self.capture_seconds = 0.0
         self.captures = 0
         self.debug_keep = False                         # tests: keep static views of a replay's draws / outputs per slot
@@ -252,6 +255,8 @@ class StepGraphs:
             E = int(b.edge_index.shape[1])
             n = max(n, int(b.x.shape[0]))
             e[E > self.q] = max(e[E > self.q], E)
+            if b.x.is_cuda and E > self.q and self.src_sorted and not ops.src_sorted(b.edge_index):
+                self.src_sorted = False                 # settled before the first capture (see forward())
             if b.x.is_cuda and E > 0:
                 self._sources(b, want_norm=E <= self.q, want_pairs=E > self.q and self.pairs_ok)   # CSR (+ unit norm / mates) of every resident partition, once
         self._set_capacity(n, e)
@@ -296,6 +301,7 @@ class StepGraphs:
         g.in_src, g.in_eid, g.out_dst, g.out_eid = (torch.zeros(max(Ecap, 1), **i32) for _ in range(4))
         g.loop_eid = torch.full((max(N, 1),), -1, **i32)
         ei._sgs_graph, ei._sgs_graph_version = g, ei._version
+        ei._sgs_src_sorted = (self.src_sorted, ei._version)
         s.graph = g
         if sampled and self.pairs_ok:
             # mates of the paired scorer forward: static buffers filled by the staging copy, their live length in dims[1]
@@ -643,6 +649,12 @@ class StepGraphs:
         """Runs the step up to the gate (E_b > q) or completely (E_b <= q) and returns the handle the trainer
         finishes the step with: `h.sampled`, `h.cbuf` (gate counts, device int32[5]) and `h.backward(learned)`.
         `next_batch` (optional): the batch of the following step; its staging copy and prefix are issued ahead."""
+        if self.src_sorted and int(batch.edge_index.shape[1]) > self.q and not ops.src_sorted(batch.edge_index):
+            # (cached on the partition's tensor: one read-back the first time a partition is seen)
+            torch.cuda.synchronize()
+            self.src_sorted = False
+            self.slots = {True: [], False: []}          # captured for source-sorted partitions: recorded again without the fused backward
+            self.stage_cache.clear()
         if not self._fits(batch):
             E = int(batch.edge_index.shape[1])
             if E == 0 or (self.nfeat not in (None, int(batch.x.shape[1]))):

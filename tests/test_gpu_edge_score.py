@@ -381,3 +381,106 @@ def test_bwd_dfeat_row_gemm_is_fp32_faithful(ops, H, n):
     print("max err / max|ref|: bf16x6", e_new, "library fp32 GEMM", e_lib)
     assert torch.isfinite(out).all()
     assert e_new <= 2 * e_lib + 1e-7
+
+
+def _sorted_case(N, H, E, q, seed, hub=6000):
+    """A row-sorted edge list (PyG's layout) with a hub source, a node range without out-edges, and a drawn subset of q edges."""
+    codes, ei, W1, b1, W2, b2, g = _case(N, H, E, seed)
+    ei = ei.clone()
+    ei[0, :hub] = 3                                          # a hub: its drawn out-edges span hundreds of 32-row tiles
+    ei[0, ei[0] % 7 == 5] = 2                                # ... and many sources without a single out-edge
+    ei = ei[:, torch.argsort(ei[0] * N + ei[1], stable=True)].contiguous()
+    eid = torch.sort(torch.randperm(E, generator=g)[:q]).values
+    return codes, ei, W1, b1, W2, b2, g, eid
+
+
+@pytest.mark.parametrize("N,H,p,q", [(777, 256, 0.3, 66_000), (777, 128, 0.0, 70_001), (1013, 256, 0.3, 100_003), (70_001, 128, 0.3, 66_000)])
+def test_fused_backward_equals_unfused_backward(ops, N, H, p, q):
+    """The fused form of the no-recompute backward (active rows sorted by source: neither feat nor dfeat is materialised, the by-source
+    half of d codes is reduced inside the dfeat contraction) against the unfused form and the dense-dv form on the same inputs."""
+    E = 140_000
+    codes, ei, W1, b1, W2, b2, g, eid = _sorted_case(N, H, E, q, 123)
+    gp = torch.zeros(E)
+    gp[eid] = torch.randn(q, generator=g)
+    sub = ei[:, eid]
+    grads = {}
+    for form, (fused, mask) in {"fused": (True, True), "unfused": (False, True), "dense": (False, False)}.items():
+        ops._fused_backward, ops._mask_backward = fused, mask
+        try:
+            dl = [t.clone().to(DEV).requires_grad_(True) for t in (codes, W1, b1, W2, b2)]
+            act = ops.ActiveSet()
+            ei_d = ei.to(DEV)
+            assert ops.src_sorted(ei_d)
+            pd = ops.edge_score(dl[0], dl[1], dl[2], dl[3], dl[4], ei_d, active=act, p=p, seed=5, site=2)
+            act.set(eid.to(DEV), ops.Graph(sub.to(DEV), N))
+            pd.backward(gp.to(DEV))
+            grads[form] = [t.grad.detach().cpu() for t in dl]
+        finally:
+            ops._fused_backward, ops._mask_backward = True, True
+    for form in ("fused", "unfused"):
+        for name, a, b in zip(["dcodes", "dW1", "db1", "dW2", "db2"], grads[form], grads["dense"]):
+            assert bool(torch.isfinite(a).all()), (form, name)
+            assert _rel(a, b) < 3e-6, (form, name, _rel(a, b))
+    # the weight gradient gathers exactly the products the materialised feat held, in the same order: bit-identical
+    assert torch.equal(grads["fused"][1][:, :H], grads["unfused"][1][:, :H])
+    assert torch.equal(grads["fused"][2], grads["unfused"][2]) and torch.equal(grads["fused"][4], grads["unfused"][4])
+
+
+@pytest.mark.parametrize("H,p,n", [(256, 0.3, 66_003), (128, 0.0, 70_000), (256, 0.0, 95)])
+def test_fused_dfeat_entry_point_by_source_partials_and_G(ops, H, p, n):
+    """sgs_edge_score_bwd_dfeat_fused through the C ABI: G == dfeat * codes[src] bit for bit (dfeat from sgs_edge_score_bwd_dfeat_bits), and
+    every node's run-end rows of `opart` add up to its by-source sum of dfeat * codes[dst]; sgs_edge_score_bwd_reduce_fused ==
+    sgs_endpoint_reduce_pair_bits to fp32 rounding."""
+    import sgs_gnn_amd as S
+    L = S._lib.lib()
+    N = 600
+    g = torch.Generator().manual_seed(H + n)
+    codes = torch.relu(torch.randn(N, H, generator=g)).to(DEV)
+    src = torch.randint(0, N, (n,), generator=g)
+    src[: min(n, 3000) // 2] = 0                                       # a long run at the start
+    src = torch.sort(src).values
+    dst = torch.randint(0, N, (n,), generator=g)
+    sub = torch.stack([src, dst]).to(DEV)
+    sd = sub.t().contiguous().to(torch.int32)
+    W1 = (torch.randn(H, 2 * H, generator=g) / (2 * H) ** 0.5).to(DEV)
+    w2 = (torch.randn(H, generator=g) / H ** 0.5).to(DEV)
+    dz = torch.randn(n, generator=g).to(DEV)
+    bits = torch.randint(-2**31, 2**31 - 1, (n, H // 32), generator=g, dtype=torch.int64).to(torch.int32).to(DEV)
+    st = ops._stream()
+    ws = ops.workspace(L.sgs_edge_score_workspace_bytes(0, H, 0), codes.device)
+    dfeat = torch.full((n, H), float("nan"), device=DEV)
+    S._lib.check(L.sgs_edge_score_bwd_dfeat_bits(bits.data_ptr(), dz.data_ptr(), n, H, W1.data_ptr(), w2.data_ptr(), p, dfeat.data_ptr(), ws.data_ptr(),
+                                                 ws.numel(), st), "dfeat_bits")
+    G = torch.full((n, H), float("nan"), device=DEV)
+    rows = L.sgs_edge_score_bwd_fused_opart_rows(n, N)
+    opart = torch.full((rows, H), float("nan"), device=DEV)
+    S._lib.check(L.sgs_edge_score_bwd_dfeat_fused(bits.data_ptr(), dz.data_ptr(), sd.data_ptr(), codes.data_ptr(), n, N, H, W1.data_ptr(), w2.data_ptr(), p,
+                                                  G.data_ptr(), opart.data_ptr(), ws.data_ptr(), ws.numel(), st), "dfeat_fused")
+    torch.cuda.synchronize()
+    assert torch.equal(G, dfeat * codes[sub[0]])
+    # run-end rows: the last row of every source inside every 32-row tile, slot (r >> 5) + src
+    r = torch.arange(n, device=DEV)
+    is_end = torch.ones(n, dtype=torch.bool, device=DEV)
+    is_end[:-1] = (sub[0, 1:] != sub[0, :-1]) | (r[:-1] % 32 == 31)
+    slots = (r[is_end] >> 5) + sub[0, is_end]
+    assert slots.unique().numel() == slots.numel() and int(slots.max()) < rows
+    got = torch.zeros(N, H, device=DEV, dtype=torch.float64)
+    got.index_add_(0, sub[0, is_end], opart[slots].double())
+    want = torch.zeros(N, H, device=DEV, dtype=torch.float64)
+    want.index_add_(0, sub[0], (dfeat * codes[sub[1]]).double())
+    assert bool(torch.isfinite(opart[slots]).all())
+    assert _rel(got.float(), want.float().cpu()) < 2e-6
+    # the reductions
+    graph = ops.Graph(sub, N)
+    assert torch.equal(graph.out_eid[:n].long(), torch.arange(n, device=DEV))        # rows sorted by source: the out-CSR is the identity
+    oc1, ou1, ur1 = (torch.full((N, H), float("nan"), device=DEV) for _ in range(3))
+    oc2, ou2, ur2 = (torch.full((N, H), float("nan"), device=DEV) for _ in range(3))
+    S._lib.check(L.sgs_endpoint_reduce_pair_bits(dfeat.data_ptr(), bits.data_ptr(), dz.data_ptr(), w2.data_ptr(), p, codes.data_ptr(), N, H, n,
+                                                 graph.in_ptr.data_ptr(), graph.in_src.data_ptr(), graph.in_eid.data_ptr(), graph.out_ptr.data_ptr(),
+                                                 graph.out_dst.data_ptr(), graph.out_eid.data_ptr(), oc1.data_ptr(), ou1.data_ptr(), ur1.data_ptr(), st),
+                 "reduce_pair_bits")
+    S._lib.check(L.sgs_edge_score_bwd_reduce_fused(G.data_ptr(), opart.data_ptr(), bits.data_ptr(), dz.data_ptr(), w2.data_ptr(), p, N, H, n,
+                                                   graph.in_ptr.data_ptr(), graph.in_eid.data_ptr(), graph.out_ptr.data_ptr(), oc2.data_ptr(), ou2.data_ptr(),
+                                                   ur2.data_ptr(), st), "reduce_fused")
+    torch.cuda.synchronize()
+    assert _rel(oc2, oc1.cpu()) < 3e-6 and _rel(ou2, ou1.cpu()) < 3e-6 and _rel(ur2, ur1.cpu()) < 3e-6
