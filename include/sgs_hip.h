@@ -422,10 +422,10 @@ int sgs_endpoint_reduce_pair_bits(const float* dfeat, const uint32_t* dvbits, co
  * before the factor rowscale * scale (terms of d fc2.weight, sgs_edge_score_dw2_from_parts).  Tall-K shapes only (sgs_gemm_tn_mask_supported);
  * ws: sgs_gemm_tn_workspace_bytes(K, M, N). */
 int sgs_gemm_tn_mask_supported(int64_t K, int64_t M, int64_t N);
-/* ... with B never materialised: row k of B = codes[src k, :] * codes[dst k, :], (src, dst) = sd[k] (int32 [K, 2]), `codes` [*, N] row-major.
+/* ... with B never materialised: row k of B = codes[src k, :] * codes[dst k, :], (src, dst) = sd[k] (int32 [K, 2]), `codes` [codes_rows, N] row-major (codes_rows * N < 2^32).
  * Bit-identical to sgs_gemm_tn_mask on the materialised rows (same products, same order). */
-int sgs_gemm_tn_mask_gather(const uint32_t* Abits, const float* dz, const float* rowscale, float scale, const float* codes, const int32_t* sd,
-                            int64_t K, int64_t M, int64_t N, float* C, int64_t ldc, float* colsum_A, float* dz_sum, float* C_raw,
+int sgs_gemm_tn_mask_gather(const uint32_t* Abits, const float* dz, const float* rowscale, float scale, const float* codes, int64_t codes_rows,
+                            const int32_t* sd, int64_t K, int64_t M, int64_t N, float* C, int64_t ldc, float* colsum_A, float* dz_sum, float* C_raw,
                             float* colsum_raw, void* ws, size_t ws_bytes, sgs_stream_t stream);
 int sgs_gemm_tn_mask(const uint32_t* Abits, const float* dz, const float* rowscale, float scale, const float* B, int64_t K, int64_t M, int64_t N,
                      float* C, int64_t ldc, float* colsum_A, float* dz_sum, float* C_raw, float* colsum_raw, void* ws, size_t ws_bytes,

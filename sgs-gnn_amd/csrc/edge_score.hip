@@ -920,18 +920,27 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
                 if (live) *reinterpret_cast<float4*>(a.feat + r * H + 8 * i + 4 * kh) = make_float4(f0 * s4.x, f1 * s4.y, f2 * s4.z, f3 * s4.w);
                 *reinterpret_cast<float4*>(ot + l31 * LS + 8 * ii + 4 * kh) = make_float4(f0 * d4.x, f1 * d4.y, f2 * d4.z, f3 * d4.w);
             }
-            __syncthreads();
+            // the tile is wave-private and a wave's LDS operations execute in issue order: no workgroup barrier, only the compiler is
+            // told not to move the reads above the writes (or the next pass's writes above these reads)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float col[32];
+#pragma unroll
+            for (int row = 0; row < 32; ++row) col[row] = ot[row * LS + lane];            // all 32 reads in flight before the (branchy) walk below
             float run = 0.f;
 #pragma unroll
             for (int row = 0; row < 32; ++row) {
-                run += ot[row * LS + lane];
+                run += col[row];
                 if ((endmask >> row) & 1u) {                                             // (wave-uniform)
                     const int64_t slot = wrow + __builtin_amdgcn_readlane(sr, row);
                     a.opart[slot * H + 64 * Q + lane] = run;
                     run = 0.f;
                 }
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         return;
     }

@@ -274,21 +274,41 @@ __global__ void __launch_bounds__(64 * NW) gemm_tn_tall_bf16x6(const float* __re
     const float* Db = MASK ? dz + k0 : nullptr;
     const float* Bb = GATHER ? B + jb : B + k0 * N + jb;
     const int2* Sb = GATHER ? reinterpret_cast<const int2*>(sd) + k0 : nullptr;
+    // 32-bit offsets from per-lane bases throughout (the codes table has < 2^31 elements: checked by the launcher); whole steps -- all
+    // but a slice's last -- take the unclamped path (wave-uniform)
     auto load_idx = [&](int64_t k, Idx& ix) {                               // (rows past the slice: its last row, neutralised through dz = 0)
         const int rel = static_cast<int>(k - k0) + 8 * g;
+        if (k + 16 <= k1) {
+            const int2* sp = Sb + rel;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ix.e[j] = Sb[max(min(rel + j, lim - 1), 0)];
+            for (int j = 0; j < 8; ++j) ix.e[j] = sp[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ix.e[j] = Sb[max(min(rel + j, lim - 1), 0)];
+        }
     };
     auto load_rows = [&](int64_t k, Raw& r, const Idx& ix) {
         r.k = k;
         const int rel = static_cast<int>(k - k0) + 8 * g;
+        if (k + 16 <= k1) {
+            const uint32_t* ap = Ab + rel * wpr;
+            const float* dp = Db + rel;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int rc = max(min(rel + j, lim - 1), 0);
-            r.aw[j] = Ab[rc * wpr];
-            r.dzr[j] = Db[rc];
-            r.b[j] = *reinterpret_cast<const float2*>(Bb + static_cast<int64_t>(ix.e[j].x) * N);
-            r.b2[j] = *reinterpret_cast<const float2*>(Bb + static_cast<int64_t>(ix.e[j].y) * N);
+            for (int j = 0; j < 8; ++j) {
+                r.aw[j] = ap[j * wpr];
+                r.dzr[j] = dp[j];
+                r.b[j] = *reinterpret_cast<const float2*>(Bb + static_cast<uint32_t>(ix.e[j].x) * static_cast<uint32_t>(N));
+                r.b2[j] = *reinterpret_cast<const float2*>(Bb + static_cast<uint32_t>(ix.e[j].y) * static_cast<uint32_t>(N));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int rc = max(min(rel + j, lim - 1), 0);
+                r.aw[j] = Ab[rc * wpr];
+                r.dzr[j] = Db[rc];
+                r.b[j] = *reinterpret_cast<const float2*>(Bb + static_cast<uint32_t>(ix.e[j].x) * static_cast<uint32_t>(N));
+                r.b2[j] = *reinterpret_cast<const float2*>(Bb + static_cast<uint32_t>(ix.e[j].y) * static_cast<uint32_t>(N));
+            }
         }
     };
     auto load = [&](int64_t k, Raw& r) {
@@ -602,10 +622,11 @@ int sgs_gemm_tn_mask(const uint32_t* Abits, const float* dz, const float* rowsca
 
 /* The same product with B = codes[src] * codes[dst] gathered per row (sd [K, 2] int32 endpoints; `codes` [*, N]): the scorer's weight
  * gradient without a materialised feat.  Bit-identical to sgs_gemm_tn_mask on the materialised rows. */
-int sgs_gemm_tn_mask_gather(const uint32_t* Abits, const float* dz, const float* rowscale, float scale, const float* codes, const int32_t* sd,
-                            int64_t K, int64_t M, int64_t N, float* C, int64_t ldc, float* colsum_A, float* dz_sum, float* C_raw,
+int sgs_gemm_tn_mask_gather(const uint32_t* Abits, const float* dz, const float* rowscale, float scale, const float* codes, int64_t codes_rows,
+                            const int32_t* sd, int64_t K, int64_t M, int64_t N, float* C, int64_t ldc, float* colsum_A, float* dz_sum, float* C_raw,
                             float* colsum_raw, void* ws, size_t ws_bytes, sgs_stream_t stream_) {
     SGS_REQUIRE(ldc >= N, SGS_EINVAL, "sgs_gemm_tn_mask_gather: ldc < N");
+    SGS_REQUIRE(codes_rows > 0 && codes_rows * N < (int64_t(1) << 32), SGS_EINVAL, "sgs_gemm_tn_mask_gather: the codes table needs 32-bit element offsets");
     SGS_REQUIRE(Abits && dz && rowscale && codes && sd, SGS_EINVAL, "sgs_gemm_tn_mask_gather: null pointer");
     SGS_REQUIRE(sgs_gemm_tn_mask_supported(K, M, N), SGS_EINVAL, "sgs_gemm_tn_mask_gather: shape not served (check sgs_gemm_tn_mask_supported)");
     SGS_REQUIRE(!colsum_raw || colsum_A, SGS_EINVAL, "sgs_gemm_tn_mask_gather: colsum_raw needs colsum_A");

@@ -833,7 +833,7 @@ def _edge_score_backward_fused(ctx, L, codes, U, W1, b1, w2, edge_index, eid, gr
     Traw, craw, Rraw = torch.empty(H, H, **f32), torch.empty(H, **f32), torch.empty(N, H, **f32)
     scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
     wsg = workspace(L.sgs_gemm_tn_workspace_bytes(n, H, H), dev)
-    _lib.check(L.sgs_gemm_tn_mask_gather(_ptr(bits), _ptr(dz), _ptr(w2), scale, _ptr(codes), _ptr(sd), n, H, H, _ptr(dW1), 2 * H, _ptr(db1), _ptr(db2),
+    _lib.check(L.sgs_gemm_tn_mask_gather(_ptr(bits), _ptr(dz), _ptr(w2), scale, _ptr(codes), N, _ptr(sd), n, H, H, _ptr(dW1), 2 * H, _ptr(db1), _ptr(db2),
                                          _ptr(Traw), _ptr(craw), wsg.data_ptr(), wsg.numel(), _stream()), "sgs_gemm_tn_mask_gather")
     dcodes, dU = torch.empty(N, H, **f32), torch.empty(N, H, **f32)
     _lib.check(L.sgs_edge_score_bwd_reduce_fused(_ptr(G), _ptr(opart), _ptr(bits), _ptr(dz), _ptr(w2), p, N, H, graph.n_edges, _ptr(graph.in_ptr),

@@ -420,7 +420,8 @@ def test_fused_backward_equals_unfused_backward(ops, N, H, p, q):
     for form in ("fused", "unfused"):
         for name, a, b in zip(["dcodes", "dW1", "db1", "dW2", "db2"], grads[form], grads["dense"]):
             assert bool(torch.isfinite(a).all()), (form, name)
-            assert _rel(a, b) < 3e-6, (form, name, _rel(a, b))
+            # (d b2 is ONE sum of q signed terms: its relative error is the summation order's, not the kernels')
+            assert _rel(a, b) < (2e-5 if name == "db2" else 3e-6), (form, name, _rel(a, b))
     # the weight gradient gathers exactly the products the materialised feat held, in the same order: bit-identical
     assert torch.equal(grads["fused"][1][:, :H], grads["unfused"][1][:, :H])
     assert torch.equal(grads["fused"][2], grads["unfused"][2]) and torch.equal(grads["fused"][4], grads["unfused"][4])

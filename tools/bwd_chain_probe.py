@@ -48,7 +48,7 @@ calls = {
                                                                             p_out.data_ptr(), maskbits.data_ptr(), dz.data_ptr(), bits.data_ptr(), sd.data_ptr(), st)),
     "FUSED dfeat_fused": lambda: ck(L.sgs_edge_score_bwd_dfeat_fused(bits.data_ptr(), dz.data_ptr(), sd.data_ptr(), codes.data_ptr(), q, N, H, W1.data_ptr(), w2.data_ptr(), p,
                                                                      G.data_ptr(), opart.data_ptr(), wsd.data_ptr(), wsd.numel(), st)),
-    "FUSED gemm_tn_mask_gather": lambda: ck(L.sgs_gemm_tn_mask_gather(bits.data_ptr(), dz.data_ptr(), w2.data_ptr(), scale, codes.data_ptr(), sd.data_ptr(), q, H, H,
+    "FUSED gemm_tn_mask_gather": lambda: ck(L.sgs_gemm_tn_mask_gather(bits.data_ptr(), dz.data_ptr(), w2.data_ptr(), scale, codes.data_ptr(), N, sd.data_ptr(), q, H, H,
                                                                       dW1.data_ptr(), 2 * H, db1.data_ptr(), db2.data_ptr(), Traw.data_ptr(), craw.data_ptr(),
                                                                       wsd.data_ptr(), wsd.numel(), st)),
     "FUSED reduce_fused": lambda: ck(L.sgs_edge_score_bwd_reduce_fused(G.data_ptr(), opart.data_ptr(), bits.data_ptr(), dz.data_ptr(), w2.data_ptr(), p, N, H, q,
