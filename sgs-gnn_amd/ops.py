@@ -608,7 +608,7 @@ def _endpoint_reduce(M_out, M_in, T, graph: Graph, s_out, s_in, H):
 
 _mask_backward = True        # False: the dense fp32 dv path at every size (tests compare the two)
 _fwd_mask = True             # False: the forward keeps no mask; the backward recomputes the hidden layer (sgs_edge_score_bwd_core_bits)
-_fused_backward = True       # False: feat / dfeat as [n, H] arrays and sgs_endpoint_reduce_pair_bits (the form for edge lists not sorted by source)
+_fused_backward = os.environ.get("SGS_FUSED_BWD", "1") != "0"   # False: feat / dfeat as [n, H] arrays and sgs_endpoint_reduce_pair_bits (the form for edge lists not sorted by source)
 
 
 def src_sorted(edge_index: torch.Tensor) -> bool:

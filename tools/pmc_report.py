@@ -14,7 +14,9 @@ def load(d):
         name = r["Kernel_Name"]
         if not needle.search(name):
             continue
-        short = re.sub(r"\(.*", "", name)
+        clean = name.replace("(anonymous namespace)::", "").replace("void ", "")
+        m = re.match(r"([\w:]+(?:<[^(]*>)?)", clean)
+        short = m.group(1) if m else clean[:60]
         k = int(r["Dispatch_Id"])
         out[short][k][r["Counter_Name"]] = out[short][k].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         dur[short][k] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
