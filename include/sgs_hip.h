@@ -245,6 +245,12 @@ int sgs_gcn_norm_bwd(const float* w, const float* gw_hat, const float* gloop, in
                      const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
                      const int32_t* loop_eid, const int64_t* edge_index, float* dw, void* ws, size_t ws_bytes,
                      sgs_stream_t stream);
+/* ... with up to two upstream gradients summed on read (gw_hat2 / gloop2: the second GCN layer over the same normalisation; both or neither)
+ * and another consumer's d w added on the way out (dw_add, optional; may be dw itself) -- the add kernels autograd would launch. */
+int sgs_gcn_norm_bwd_sum(const float* w, const float* gw_hat, const float* gloop, const float* gw_hat2, const float* gloop2, const float* dw_add,
+                         int64_t n_edges, int64_t N, const float* dis, const float* loopw, const int32_t* in_ptr, const int32_t* in_src,
+                         const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
+                         const int32_t* loop_eid, const int64_t* edge_index, float* dw, void* ws, size_t ws_bytes, sgs_stream_t stream);
 
 /* Split form of sgs_gcn_norm_bwd for edge-sharded graphs: Hn (per node) is linear in the edge contributions, so
  * each rank computes its partial Hn (gloop non-zero only on the rank that owns the self-loop term), the host
@@ -579,6 +585,16 @@ int sgs_er_weight(const int64_t* edge_index, int64_t E, int64_t N, const int32_t
 int sgs_adam_max_tensors(void);
 int sgs_adam_step(const int64_t* desc_host, int64_t n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
                   int maximize, uint32_t* ticket, sgs_stream_t stream);
+/* Several optimisers' steps in ONE launch, plus the step's closing bookkeeping (round 3).  training_hybrid.py:136-137 steps
+ * optimizer_edge_prob and then optimizer_gnn; the two overlap on edge_prob_mlp.gcn* (main.py:100-109, 122), so those tensors are updated
+ * twice with the same gradient.  A descriptor names a tensor once and carries one or two optimiser states, applied in order:
+ *   desc_host  [n_tensors][11] int64: {param, grad, numel, exp_avg, exp_avg_sq, step, gate, exp_avg2, exp_avg_sq2, step2, gate2}
+ *              (exp_avg2 == 0: one state; gates as in sgs_adam_step)
+ *   hyper_host [n_tensors][12] float: {lr, beta1, beta2, eps, weight_decay, maximize} of the first state, then of the second
+ * loss_sum / loss / epoch (each pair optional): the last workgroup also does what sgs_loss_tick does.  n_tensors <= sgs_adam_multi_max_tensors(). */
+int sgs_adam_multi_max_tensors(void);
+int sgs_adam_step_multi(const int64_t* desc_host, const float* hyper_host, int64_t n_tensors, uint32_t* ticket, float* loss_sum, const float* loss,
+                        uint64_t* epoch, sgs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -473,7 +473,10 @@ __global__ void __launch_bounds__(kT) norm_bwd_node(const float* __restrict__ w,
                                                    const int* __restrict__ in_src, const int* __restrict__ in_eid,
                                                    const int* __restrict__ out_ptr, const int* __restrict__ out_dst,
                                                    const int* __restrict__ out_eid, const float* __restrict__ dis,
-                                                   const float* __restrict__ loopw, float* __restrict__ Hn) {
+                                                   const float* __restrict__ loopw, float* __restrict__ Hn,
+                                                   const float* __restrict__ gw2 = nullptr, const float* __restrict__ gloop2 = nullptr) {
+    // gw2 / gloop2 (optional): a second layer's gradient wrt the same normalised weights, summed on read (both GCN layers of a model
+    // share one normalisation: autograd's add kernel between the two SDDMMs and this pass is not needed)
     const int lane = threadIdx.x & 63;
     const int64_t t = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
     if (t >= N) return;
@@ -484,7 +487,8 @@ __global__ void __launch_bounds__(kT) norm_bwd_node(const float* __restrict__ w,
         for (int k0 = b; k0 < e_; k0 += 64) {
             const int k = k0 + lane, kc = min(k, e_ - 1);
             const int s = col[kc], e = eid[kc];
-            const float v = gw[e] * w[e] * dis[s];
+            const float ge = gw2 ? gw[e] + gw2[e] : gw[e];
+            const float v = ge * w[e] * dis[s];
             if (k < e_ && s != static_cast<int>(t)) acc += v;
         }
     };
@@ -493,7 +497,8 @@ __global__ void __launch_bounds__(kT) norm_bwd_node(const float* __restrict__ w,
     acc = wave_sum_all(acc);
     if (lane == 0) {
         const float a = dis[t];
-        const float G = acc + 2.0f * gloop[t] * loopw[t] * a;
+        const float gl = gloop2 ? gloop[t] + gloop2[t] : gloop[t];
+        const float G = acc + 2.0f * gl * loopw[t] * a;
         Hn[t] = -0.5f * a * a * a * G;
     }
 }
@@ -501,15 +506,18 @@ __global__ void __launch_bounds__(kT) norm_bwd_node(const float* __restrict__ w,
 __global__ void __launch_bounds__(kT) norm_bwd_edge(const float* __restrict__ gw, const float* __restrict__ gloop,
                                                    const int64_t* __restrict__ ei, int64_t n_edges,
                                                    const int* __restrict__ loop_eid, const float* __restrict__ dis,
-                                                   const float* __restrict__ Hn, float* __restrict__ dw) {
+                                                   const float* __restrict__ Hn, float* __restrict__ dw,
+                                                   const float* __restrict__ gw2 = nullptr, const float* __restrict__ gloop2 = nullptr,
+                                                   const float* __restrict__ dw_add = nullptr) {
+    // dw_add (optional, may alias dw): another consumer's gradient wrt the same edge weights, added on the way out
     const int64_t e = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
     if (e >= n_edges) return;
     const int s = static_cast<int>(ei[e]), t = static_cast<int>(ei[n_edges + e]);
     float g;
-    if (s != t) g = gw[e] * dis[s] * dis[t] + Hn[t];
-    else g = gloop[s] * dis[s] * dis[s] + Hn[s];   // every existing (i,i) edge: PyG's index_put backward hands
-                                                   // the loop gradient to overwritten duplicates too
-    dw[e] = g;
+    if (s != t) g = (gw2 ? gw[e] + gw2[e] : gw[e]) * dis[s] * dis[t] + Hn[t];
+    else g = (gloop2 ? gloop[s] + gloop2[s] : gloop[s]) * dis[s] * dis[s] + Hn[s];   // every existing (i,i) edge: PyG's index_put backward hands
+                                                                                     // the loop gradient to overwritten duplicates too
+    dw[e] = dw_add ? g + dw_add[e] : g;
 }
 
 // ---------------------------------------------------------------- CSR SpMM:  Y[i,:] = act( sum_k val[k] X[col[k],:] + diag[i] X[i,:] + bias )
@@ -1192,6 +1200,28 @@ int sgs_gcn_norm_bwd(const float* w, const float* gw_hat, const float* gloop, in
                        out_ptr, out_dst, out_eid, dis, loopw, Hn);
     hipLaunchKernelGGL(norm_bwd_edge, dim3(cdiv(n_edges, kT)), dim3(kT), 0, stream, gw_hat, gloop, edge_index, n_edges, loop_eid,
                        dis, Hn, dw);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+/* The same with up to two upstream gradients summed on read (gw_hat2 / gloop2: the second GCN layer over the same normalisation) and
+ * another consumer's d w added on the way out (dw_add, may be dw itself: in-place accumulation) -- the adds autograd would launch. */
+int sgs_gcn_norm_bwd_sum(const float* w, const float* gw_hat, const float* gloop, const float* gw_hat2, const float* gloop2, const float* dw_add,
+                         int64_t n_edges, int64_t N, const float* dis, const float* loopw, const int32_t* in_ptr, const int32_t* in_src,
+                         const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
+                         const int32_t* loop_eid, const int64_t* edge_index, float* dw, void* ws, size_t ws_bytes, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && n_edges >= 0, SGS_EINVAL, "sgs_gcn_norm_bwd_sum: bad sizes");
+    if (N == 0 || n_edges == 0) return SGS_OK;
+    SGS_REQUIRE(w && gw_hat && gloop && dis && loopw && dw && edge_index && ((gw_hat2 != nullptr) == (gloop2 != nullptr)), SGS_EINVAL,
+                "sgs_gcn_norm_bwd_sum: null pointer");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_gcn_norm_bwd_workspace_bytes(N), SGS_EWORKSPACE, "sgs_gcn_norm_bwd_sum: workspace too small");
+    Carver cv(ws);
+    float* Hn = cv.take<float>(N);
+    hipLaunchKernelGGL(norm_bwd_node, dim3(cdiv(N * 64, kT)), dim3(kT), 0, stream, w, gw_hat, gloop, N, in_ptr, in_src, in_eid,
+                       out_ptr, out_dst, out_eid, dis, loopw, Hn, gw_hat2, gloop2);
+    hipLaunchKernelGGL(norm_bwd_edge, dim3(cdiv(n_edges, kT)), dim3(kT), 0, stream, gw_hat, gloop, edge_index, n_edges, loop_eid,
+                       dis, Hn, dw, gw_hat2, gloop2, dw_add);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

@@ -434,7 +434,7 @@ class Norm:
     """gcn_norm result for (graph, w): dis, loopw and the normalised weights in both CSR orders.
     `handle` is the autograd edge through which the layers' gradients wrt the normalised
     weights ([n_edges] edge order + [N] loops) flow back to `w`; its storage is never read."""
-    __slots__ = ("graph", "w", "dis", "loopw", "what_in", "what_out", "what_loop", "handle")
+    __slots__ = ("graph", "w", "dis", "loopw", "what_in", "what_out", "what_loop", "handle", "_g_first", "_g_extra", "_dw_first", "_park_ok", "__weakref__")
 
 
 def _norm_forward(graph: Graph, w):
@@ -470,17 +470,48 @@ class _GCNNorm(torch.autograd.Function):
         L = _lib.lib()
         nm, gr = ctx.nm, ctx.nm.graph
         g = g.contiguous()
-        dw = torch.empty(gr.n_edges, dtype=torch.float32, device=g.device)
-        if gr.n_edges > 0:
-            gw, gl = g[:gr.n_edges], g[gr.n_edges:]
+        n = gr.n_edges
+        # side bands (see _handle_grad / note_first_dw): a second layer's gradient wrt the normalised weights is summed on read, and the
+        # edge weights' other consumer's d w (the loss's regularisers) is accumulated IN PLACE -- two autograd add launches less
+        extra = getattr(nm, "_g_extra", None)
+        nm._g_first = nm._g_extra = None
+        first = getattr(nm, "_dw_first", None)
+        first = first() if first is not None else None
+        nm._dw_first = None
+        if first is not None and (first.numel() != n or not first.is_contiguous() or first.dtype != torch.float32):
+            first = None
+        dw = first if first is not None else torch.empty(n, dtype=torch.float32, device=g.device)
+        if n > 0:
+            gw, gl = g[:n], g[n:]
+            g2w = g2l = None
+            if extra is not None and extra.numel() == g.numel():
+                g2w, g2l = extra[:n].data_ptr(), extra[n:].data_ptr()
+            elif extra is not None:
+                g = g + extra
+                gw, gl = g[:n], g[n:]
             nws = L.sgs_gcn_norm_bwd_workspace_bytes(gr.N)
             ws = workspace(nws, g.device)
-            _lib.check(L.sgs_gcn_norm_bwd(_ptr(nm.w), gw.data_ptr(), gl.data_ptr(), gr.n_edges, gr.N, _ptr(nm.dis),
-                                          _ptr(nm.loopw), _ptr(gr.in_ptr), _ptr(gr.in_src), _ptr(gr.in_eid),
-                                          _ptr(gr.out_ptr), _ptr(gr.out_dst), _ptr(gr.out_eid), _ptr(gr.loop_eid),
-                                          _ptr(gr.edge_index), _ptr(dw), ws.data_ptr(), ws.numel(), _stream()),
-                       "sgs_gcn_norm_bwd")
-        return dw, None, None
+            _lib.check(L.sgs_gcn_norm_bwd_sum(_ptr(nm.w), gw.data_ptr(), gl.data_ptr(), g2w, g2l, None if first is None else first.data_ptr(), n, gr.N,
+                                              _ptr(nm.dis), _ptr(nm.loopw), _ptr(gr.in_ptr), _ptr(gr.in_src), _ptr(gr.in_eid), _ptr(gr.out_ptr),
+                                              _ptr(gr.out_dst), _ptr(gr.out_eid), _ptr(gr.loop_eid), _ptr(gr.edge_index), _ptr(dw), ws.data_ptr(),
+                                              ws.numel(), _stream()), "sgs_gcn_norm_bwd_sum")
+        return (None if first is not None else dw), None, None
+
+
+def _handle_grad(nm, g):
+    """What a layer's backward returns for the normalisation's handle.  Both layers of a model share one Norm; autograd would add their two
+    gradients with a launch of its own before _GCNNorm.backward.  Instead the first layer to finish returns its gradient as usual and the
+    second parks its own on the Norm (summed on read by sgs_gcn_norm_bwd_sum) and returns None.  Nothing can get lost: the parked gradient
+    has exactly one consumer, _GCNNorm.backward, which runs after every layer over the Norm has reported."""
+    if not getattr(nm, "_park_ok", False):             # only Norms whose backward (_GCNNorm) reads the side band
+        return g
+    if getattr(nm, "_g_first", None) is None:
+        nm._g_first = g
+        return g
+    if getattr(nm, "_g_extra", None) is None:
+        nm._g_extra = g
+        return None
+    return g
 
 
 def gcn_norm(graph: Graph, w=None) -> Norm:
@@ -501,6 +532,12 @@ def gcn_norm(graph: Graph, w=None) -> Norm:
     handle = _GCNNorm.apply(w, graph, box)
     nm = box[0]
     nm.handle = handle
+    nm._park_ok = True
+    try:
+        import weakref
+        w._sgs_norm = weakref.ref(nm)          # (note_first_dw: the loss finds the normalisation that differentiates these weights)
+    except Exception:
+        pass
     return nm
 
 
@@ -550,7 +587,7 @@ class _Propagate(torch.autograd.Function):
                                        gw.data_ptr(), gl.data_ptr(), _stream()), "sgs_sddmm_csr")
         if want_db and dbias is None:
             dbias = _colsum(dZ)
-        return dX, g, dbias, None, None, None, None, None
+        return dX, (_handle_grad(nm, g) if g is not None else None), dbias, None, None, None, None, None
 
 
 def gcn_propagate(X, nm: Norm, bias=None, act=ACT_NONE, p=0.0, seed=0, site=0):
@@ -1041,6 +1078,7 @@ class _HybridLoss(torch.autograd.Function):
                                          _ptr(row_lse), _ptr(rowloss), _ptr(n_rows), ws.data_ptr(), ws.numel(), _stream()), "sgs_hybrid_loss_fwd")
         ctx.save_for_backward(logits, y, mask_u8, w, sei, out, row_lse, n_rows)
         ctx.graph, ctx.coef1, ctx.coef2 = graph, float(coef1), float(coef2)
+        ctx.nm_ref = getattr(w, "_sgs_norm", None)         # the normalisation that differentiates these weights, if any (note_first_dw)
         box.append(out)
         return out[6]
 
@@ -1065,6 +1103,10 @@ class _HybridLoss(torch.autograd.Function):
             dlogits = torch.empty_like(logits)
             _lib.check(L.sgs_masked_ce_bwd(_ptr(logits), N, C, _ptr(y), _ptr(mask_u8), _ptr(row_lse), _ptr(n_rows), _ptr(g), _ptr(dlogits),
                                            _stream()), "sgs_masked_ce_bwd")
+        nm = ctx.nm_ref() if ctx.nm_ref is not None else None
+        if nm is not None and getattr(nm, "_park_ok", False) and dw.numel() == nm.graph.n_edges:
+            import weakref
+            nm._dw_first = weakref.ref(dw)                 # the normalisation's backward accumulates into dw in place (no autograd add)
         return dlogits, None, None, dw, None, None, None, None, None
 
 
@@ -1289,7 +1331,7 @@ class _GCNLayer(torch.autograd.Function):
                                        gw.data_ptr(), gl.data_ptr(), _stream()), "sgs_sddmm_csr")
         if want_db and dbias is None:
             dbias = _colsum(dZ)
-        return dx, dW, g, dbias, None, None, None, None, None, None
+        return dx, dW, (_handle_grad(nm, g) if g is not None else None), dbias, None, None, None, None, None, None
 
 
 def gcn_layer(x, W, bias, nm: Norm, act=ACT_NONE, p=0.0, seed=0, site=0, xl=None):

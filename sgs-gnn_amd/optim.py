@@ -88,3 +88,78 @@ class FusedAdam(torch.optim.Optimizer):
                 if not torch.cuda.is_current_stream_capturing():
                     torch.autograd.graph.increment_version(part)
         return loss
+
+    @staticmethod
+    @torch.no_grad()
+    def step_many(optimizers, tick=None):
+        """`for o in optimizers: o.step()` as ONE launch (sgs_adam_step_multi): a tensor that several of the optimisers hold -- the
+        reference's two Adam objects overlap on edge_prob_mlp.gcn*, main.py:100-109, 122 -- is updated once per optimiser, in order,
+        while its elements are in registers.  `tick` = (loss_sum, loss, epoch): the launch also closes a replayed step (ops.loss_tick).
+        Falls back to separate steps for anything the fused launch does not cover (a tensor in more than two optimisers)."""
+        opts = list(optimizers)
+        L = _lib.lib()
+        order, states = [], {}
+        for o in opts:
+            if not isinstance(o, FusedAdam):
+                raise RuntimeError("FusedAdam.step_many: every optimiser must be a FusedAdam")
+            for group in o.param_groups:
+                for p in group["params"]:
+                    if p.grad is None:
+                        continue
+                    if id(p) not in states:
+                        states[id(p)] = []
+                        order.append(p)
+                    states[id(p)].append((o, group))
+        if any(len(v) > 2 for v in states.values()):
+            for o in opts:
+                o.step()
+            if tick is not None:
+                ops.loss_tick(*tick)
+            return
+        tick_ptrs = (None, None, None)
+        if tick is not None:
+            loss_sum, loss, epoch = tick
+            tick_ptrs = (loss_sum.data_ptr(), loss.detach().reshape(1).data_ptr(), epoch.data_ptr())
+        kmax = L.sgs_adam_multi_max_tensors()
+        stream = ops._stream()
+        first = opts[0]
+        if not order:
+            if tick is not None:
+                ops.loss_tick(*tick)
+            return
+        for lo in range(0, len(order), kmax):
+            part = order[lo:lo + kmax]
+            words, hyper = [], []
+            for p in part:
+                g = p.grad
+                if (p.dtype != torch.float32 or g.dtype != torch.float32 or not p.is_cuda or g.is_sparse or not p.is_contiguous()
+                        or not g.is_contiguous()):
+                    raise RuntimeError("FusedAdam: parameters and gradients must be dense, contiguous float32 HIP tensors")
+                w = [p.data_ptr(), g.data_ptr(), p.numel()]
+                h = []
+                for o, group in states[id(p)]:
+                    st = o._init_state(p)
+                    w += [st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), 0]
+                    b1, b2 = group["betas"]
+                    h += [float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), float(bool(group["maximize"]))]
+                if len(states[id(p)]) == 1:
+                    w += [0, 0, 0, 0]
+                    h += [0.0] * 6
+                words += w
+                hyper += h
+            key = ("multi", lo, tuple(id(o) for o in opts))
+            tk = first._tickets.get(key)
+            if tk is None:
+                if first._ticket_pool is not None and len(first._tickets) < first._ticket_pool.numel():
+                    i = len(first._tickets)
+                    tk = first._tickets[key] = first._ticket_pool[i:i + 1]
+                else:
+                    tk = first._tickets[key] = torch.zeros(1, dtype=torch.int32, device=part[0].device)
+            last = lo + kmax >= len(order)
+            arr = (ctypes.c_int64 * len(words))(*words)
+            hy = (ctypes.c_float * len(hyper))(*hyper)
+            tp = tick_ptrs if last else (None, None, None)
+            _lib.check(L.sgs_adam_step_multi(arr, hy, len(part), tk.data_ptr(), tp[0], tp[1], tp[2], stream), "sgs_adam_step_multi")
+            if not torch.cuda.is_current_stream_capturing():
+                torch.autograd.graph.increment_version(part)
+

@@ -538,9 +538,7 @@ class StepGraphs:
                 out = self.model(batch, batch.edge_index)
                 c.loss = _ce(self.criterion, out, batch)
                 c.loss.backward(gradient=self.one)
-                if self.optimizers is not None and not self.dp:
-                    self.optimizers[1].step()                      # optimizer_gnn (training_hybrid.py:161)
-                ops.loss_tick(self.loss_sum, c.loss, self.epoch_word)     # + RNG epoch: the next replay draws fresh noise
+                self._steps_and_tick((self.optimizers[1],) if (self.optimizers is not None and not self.dp) else (), c.loss)   # optimizer_gnn (training_hybrid.py:161)
             c.grads = self._grads()
             c.loss = c.loss.detach()
             self._clear_grads()
@@ -579,10 +577,8 @@ class StepGraphs:
             loss_l.backward(gradient=self.one, retain_graph=st.random_out is not None)
             if self.dp:
                 self.sync.flag.fill_(1.0)                          # this rank's gate chose "learned"
-            elif self.optimizers is not None:
-                self.optimizers[0].step()                          # optimizer_edge_prob, then optimizer_gnn (:136-137)
-                self.optimizers[1].step()
-            ops.loss_tick(self.loss_sum, loss_l, self.epoch_word)
+            # optimizer_edge_prob, then optimizer_gnn (:136-137), and the step's closing tick: one launch with FusedAdam
+            self._steps_and_tick(tuple(self.optimizers) if (self.optimizers is not None and not self.dp) else (), loss_l)
         c.grads_l = self._grads()
         c.loss_l = loss_l.detach()
         self._clear_grads()
@@ -596,12 +592,21 @@ class StepGraphs:
                     self.sync.flat.zero_()
                 loss_r = _ce(self.criterion, st.random_out, batch)
                 loss_r.backward(gradient=self.one)
-                if self.optimizers is not None and not self.dp:
-                    self.optimizers[1].step()                      # optimizer_gnn only (:141)
-                ops.loss_tick(self.loss_sum, loss_r, self.epoch_word)
+                self._steps_and_tick((self.optimizers[1],) if (self.optimizers is not None and not self.dp) else (), loss_r)   # optimizer_gnn only (:141)
             c.grads_r = self._grads()
             c.loss_r = loss_r.detach()
             self._clear_grads()
+
+    def _steps_and_tick(self, opts, loss) -> None:
+        """The optimiser steps a backward graph ends with, then `loss_sum += loss; epoch += 1` (the RNG epoch: the next replay draws
+        fresh noise).  FusedAdam optimisers: ONE launch for all of it (sgs_adam_step_multi); others: their own step() + sgs_loss_tick."""
+        from .optim import FusedAdam
+        if opts and all(isinstance(o, FusedAdam) for o in opts):
+            FusedAdam.step_many(opts, tick=(self.loss_sum, loss, self.epoch_word))
+            return
+        for o in opts:
+            o.step()
+        ops.loss_tick(self.loss_sum, loss, self.epoch_word)
 
     # ------------------------------------------------------------------ one step
     def _set_grads(self, grads):

@@ -149,3 +149,50 @@ def test_evaluate_after_a_replayed_epoch_sees_the_current_weights():
     b2 = S.Batch(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.__dict__.items() if not k.startswith("_sgs")})
     ev2 = S.ensemble_evaluate(args, fresh, [b2], DEV, q=2000, mode="learned")
     assert ev == ev2
+
+
+def test_step_many_equals_sequential_steps_of_overlapping_optimisers_and_ticks():
+    """FusedAdam.step_many((oe, og), tick=...) == oe.step(); og.step(); loss_tick(...) in ONE launch: the two optimisers of the reference
+    overlap (main.py:100-109, 122: 'gcn' also matches edge_prob_mlp.gcn*), the shared tensors step twice per call with the same gradient,
+    tensors without a gradient are skipped, different hyper-parameters per optimiser are honoured; also replayed from a HIP graph."""
+    import sgs_gnn_amd as S
+    shapes = [(40, 9), (300,), (33, 5), (2100,), (7,)]
+    pa, pb = _params(5, shapes), _params(5, shapes)
+    # optimiser 1 holds tensors 0, 1, 2; optimiser 2 holds 1, 2, 3, 4 (1 and 2 shared)
+    oa1 = torch.optim.Adam([pa[0], pa[1], pa[2]], lr=2e-3, betas=(0.9, 0.99), weight_decay=1e-3)
+    oa2 = torch.optim.Adam([pa[1], pa[2], pa[3], pa[4]], lr=1e-2)
+    ob1 = S.FusedAdam([pb[0], pb[1], pb[2]], lr=2e-3, betas=(0.9, 0.99), weight_decay=1e-3)
+    ob2 = S.FusedAdam([pb[1], pb[2], pb[3], pb[4]], lr=1e-2)
+    loss_sum = torch.zeros((), device=DEV)
+    loss = torch.full((), 0.25, device=DEV)
+    epoch = torch.full((1,), 7, dtype=torch.int64, device=DEV)
+    g = torch.Generator().manual_seed(3)
+    for it in range(4):
+        grads = [torch.randn(a.shape, generator=g).to(DEV) for a in pa]
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            has = not (it == 2 and i == 4)                       # one step where tensor 4 has no gradient
+            a.grad = grads[i].clone() if has else None
+            b.grad = grads[i].clone() if has else None
+        oa1.step(); oa2.step()
+        S.FusedAdam.step_many((ob1, ob2), tick=(loss_sum, loss, epoch))
+    torch.cuda.synchronize()
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-7)
+    assert float(loss_sum) == 1.0 and int(epoch) == 11
+    assert float(ob1.state[pb[1]]["step"]) == 4.0 and float(ob2.state[pb[1]]["step"]) == 4.0 and float(ob2.state[pb[4]]["step"]) == 3.0
+    # captured: the same launch replayed
+    for a, b in zip(pa, pb):
+        a.grad = torch.ones_like(a)
+        b.grad = torch.ones_like(b)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    gph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gph, stream=s):
+        S.FusedAdam.step_many((ob1, ob2), tick=(loss_sum, loss, epoch))
+    for _ in range(3):
+        oa1.step(); oa2.step()
+        gph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-7)
+    assert float(loss_sum) == 1.75 and int(epoch) == 14
