@@ -393,6 +393,32 @@ int sgs_edge_score_bwd_prep(const float* codes, int64_t N, int64_t H, const int6
                             float* feat, sgs_stream_t stream);
 int sgs_edge_score_dw2_from_parts(const float* W1, const float* T_raw, const float* U, const float* R_raw, const float* b1, const float* c_raw,
                                   int64_t N, int64_t H, float p_drop, float* dw2, sgs_stream_t stream);
+/* ---- Endpoint-dropout scorer: EdgeProbMLP with dropout > 0 (model.py:16-45) ----
+ * The reference drops the two endpoint codes of every scored edge independently, x = drop(relu(fcdim(X[src]))), y = drop(relu(fcdim(X[dst]))),
+ * before `_edge_score(x, y)`.  relu(fcdim(.)) is row-wise and hoisted to the nodes (A [N, H]); the masks are per (edge, endpoint):
+ *   keep_x[e, c] = sgs_dropout_keep(seed_x, site_x, row e, col c),  keep_y likewise,  x_m = A[src e] * keep_x / (1 - p_ep),  y_m = ... .
+ * Masked codes differ per edge, so fc1's node-level half U[s] - U[d] does not exist: the kernels contract all 2H features [x_m * y_m | x_m - y_m]
+ * against W1 [H, 2H] per edge (fp32 MFMA, LDS-tiled) and never materialise an [E, H] array in the forward.  H % 16 == 0.
+ *   sgs_edge_score_epd_fwd       p_out [E]
+ *   sgs_edge_score_epd_bwd_core  over the active rows: dv [n, H], hdz_part [cdiv(n, 64), H], dz [n], feat2 [n, 2H] (the features)
+ *                                (then d W1 = dv^T feat2 by sgs_gemm_tn, dfeat2 = dv W1 by a library GEMM)
+ *   sgs_edge_score_epd_reduce    d A [N, H] from dfeat2 [n, 2H] over both CSR orientations of the active edge list (masks recomputed)
+ * ws: sgs_edge_score_epd_workspace_bytes(H). */
+size_t sgs_edge_score_epd_workspace_bytes(int64_t H);
+int sgs_edge_score_epd_fwd(const float* A, int64_t N, int64_t H, const int64_t* edge_index, int64_t E, int64_t edge_id_offset, const float* W1,
+                           const float* b1, const float* w2, const float* b2, float p_hidden, uint64_t seed, uint32_t site, float p_ep,
+                           uint64_t seed_x, uint32_t site_x, uint64_t seed_y, uint32_t site_y, float* p_out, void* ws, size_t ws_bytes,
+                           sgs_stream_t stream);
+int sgs_edge_score_epd_bwd_core(const float* A, int64_t N, int64_t H, const int64_t* edge_index, int64_t E, int64_t edge_id_offset,
+                                const int64_t* active_eid, int64_t n_active, const float* grad_p, const float* W1, const float* b1, const float* w2,
+                                const float* b2, float p_hidden, uint64_t seed, uint32_t site, float p_ep, uint64_t seed_x, uint32_t site_x,
+                                uint64_t seed_y, uint32_t site_y, float* dv, float* hdz_part, float* dz, float* feat2, void* ws, size_t ws_bytes,
+                                sgs_stream_t stream);
+int sgs_edge_score_epd_reduce(const float* dfeat2, const float* A, int64_t N, int64_t H, const int32_t* in_ptr, const int32_t* in_src,
+                              const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
+                              const int64_t* active_eid, int64_t edge_id_offset, float p_ep, uint64_t seed_x, uint32_t site_x, uint64_t seed_y,
+                              uint32_t site_y, float* dA, sgs_stream_t stream);
+
 /* FUSED form of the same backward (round 3), for active rows SORTED BY SOURCE (a drawn subset of a row-sorted edge list, in edge order: every
  * dataset of the reference, datasets.py:189-190 to_undirected emits a coalesced list).  Neither feat nor dfeat exists as an [n, H] array:
  *   sgs_edge_score_bwd_prep_sd        as sgs_edge_score_bwd_prep without feat; sd [n, 2] int32 = the endpoints of every active row

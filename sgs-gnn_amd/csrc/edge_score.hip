@@ -42,6 +42,22 @@ __global__ void __launch_bounds__(kT) transpose_w1a(const float* __restrict__ W1
     }
 }
 
+// W1 [H][2H] -> WT [k][h] = W1[h][k], k < 2H (endpoint-dropout variant: no node-level split)
+__global__ void __launch_bounds__(kT) transpose_w1_full(const float* __restrict__ W1, int H, float* __restrict__ WT) {
+    __shared__ float t[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;   // bx: k block (0 .. 2H), by: h block
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int h = by + r, k = bx + tx;
+        t[r][tx] = (h < H && k < 2 * H) ? W1[static_cast<int64_t>(h) * 2 * H + k] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int k = bx + r, h = by + tx;
+        if (k < 2 * H && h < H) WT[static_cast<int64_t>(k) * H + h] = t[tx][r];
+    }
+}
+
 struct ScoreArgs {
     const float* codes;      // [N,H]
     const float* U;          // [N,H] = codes W1b^T
@@ -74,6 +90,11 @@ struct ScoreArgs {
     uint32_t* dvbits;        // backward (MODE 1), optional: [n, H/32] bit h of row r = [dropped hidden h of row r > 0] -- with dz and w2 that IS dv
     const uint32_t* inbits;  // MODE 4 / 5 (dfeat from the mask): [n, H/32]
     const float* indz;       // MODE 4 / 5: [n]
+    int epd;                 // endpoint dropout (EdgeProbMLP, model.py:21-25): x = drop(A[src]), y = drop(A[dst]) per (edge, endpoint); K = 2H, no U term
+    uint64_t seed_x, seed_y; // ... their mask streams (sites site_x / site_y, row = edge id)
+    uint32_t site_x, site_y;
+    float ep_scale;          // 1 / (1 - p_endpoint)
+    uint32_t ep_thresh;
     const int32_t* sd;       // MODE 5: [n, 2] (src, dst) of every active row
     float* opart;            // MODE 5: [cdiv(n, 32) + N, H] run-end partial sums of dfeat * codes[dst] (see the kernel)
 };
@@ -83,7 +104,10 @@ struct ScoreArgs {
 // small enough that three independent workgroups share a CU and hide each other's tile staging,
 // prologue and epilogue behind MFMAs.  EXACT: H == 32*NT (the production H = 256): every bounds
 // check on k / h folds away.
-template <int NT, bool BWD, bool EXACT>
+// EPD (endpoint dropout, EdgeProbMLP with dropout > 0): the endpoint codes are masked per (edge, endpoint) before the features are
+// formed, so the node-level split U[s] - U[d] does not exist: the contraction runs over all 2H features -- k < H: x_m * y_m against
+// W1[:, k], k >= H: x_m - y_m against W1[:, k] (WaT is then the full [2H][H] transpose) -- and BWD writes feat [n, 2H].
+template <int NT, bool BWD, bool EXACT, bool EPD = false>
 __global__ void __launch_bounds__(kT, 3) edge_score_kernel(ScoreArgs a) {
     constexpr int HP = 32 * NT;
     constexpr int NTW = NT / 2;                                   // tiles per wave
@@ -132,21 +156,38 @@ __global__ void __launch_bounds__(kT, 3) edge_score_kernel(ScoreArgs a) {
     float4 wreg[kWV], xreg, yreg;
     const int fe = tid & (kBM - 1), fc = tid >> 6;           // this thread's (edge, float4 chunk) of the feature tile
     const int my_s = s_idx[fe], my_d = d_idx[fe];
+    const int KT = EPD ? 2 * H : H;                          // contraction length
+    uint32_t rkx = 0u, rky = 0u;                             // EPD: this thread's edge's mask rows for the two endpoints
+    if (EPD) {
+        const int64_t r_ = row0 + fe;
+        const int64_t e_ = r_ < a.n ? (a.active ? a.active[r_] : r_) : 0;
+        rkx = dropout_row_key(fold_epoch(a.seed_x, a.epoch), a.site_x, static_cast<uint64_t>(a.row_offset + e_));
+        rky = dropout_row_key(fold_epoch(a.seed_y, a.epoch), a.site_y, static_cast<uint64_t>(a.row_offset + e_));
+    }
+    auto ep_mask = [&](float4& v, uint32_t rk, int kk) {     // v <- v * keep / (1 - p) on columns kk .. kk + 3 (kk % 4 == 0)
+        const uint32_t b0 = dropout_pair_bits(rk, static_cast<uint32_t>(kk >> 1)), b1 = dropout_pair_bits(rk, static_cast<uint32_t>((kk >> 1) + 1));
+        v.x = (b0 & 0xFFFFu) >= a.ep_thresh ? v.x * a.ep_scale : 0.f;
+        v.y = (b0 >> 16) >= a.ep_thresh ? v.y * a.ep_scale : 0.f;
+        v.z = (b1 & 0xFFFFu) >= a.ep_thresh ? v.z * a.ep_scale : 0.f;
+        v.w = (b1 >> 16) >= a.ep_thresh ? v.w * a.ep_scale : 0.f;
+    };
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < kWV; ++j) {
             const int i = j * kT + tid;
             const int k = i / (HP / 4), h4 = (i % (HP / 4)) * 4;
             wreg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (EXACT || (i < kBK * (HP / 4) && k0 + k < H && h4 < H))
+            if (EXACT || (i < kBK * (HP / 4) && k0 + k < KT && h4 < H))
                 wreg[j] = *reinterpret_cast<const float4*>(a.WaT + static_cast<int64_t>(k0 + k) * H + h4);
         }
-        const int kk = k0 + 4 * fc;
+        const int kf = k0 + 4 * fc;                              // feature index (0 .. KT - 1)
+        const int kk = (EPD && kf >= H) ? kf - H : kf;           // column of the codes it is formed from
         xreg = make_float4(0.f, 0.f, 0.f, 0.f);
         yreg = xreg;
-        if (EXACT || kk < H) {
+        if (EXACT || kf < KT) {
             xreg = *reinterpret_cast<const float4*>(a.codes + static_cast<int64_t>(my_s) * H + kk);
             yreg = *reinterpret_cast<const float4*>(a.codes + static_cast<int64_t>(my_d) * H + kk);
+            if (EPD && a.epd) { ep_mask(xreg, rkx, kk); ep_mask(yreg, rky, kk); }
         }
     };
     auto commit = [&](int k0, int buf) {
@@ -160,11 +201,13 @@ __global__ void __launch_bounds__(kT, 3) edge_score_kernel(ScoreArgs a) {
                 *reinterpret_cast<float4*>(Wt_s + k * HP + h4) = wreg[j];
             }
         }
-        const float4 f = make_float4(xreg.x * yreg.x, xreg.y * yreg.y, xreg.z * yreg.z, xreg.w * yreg.w);
+        const bool diff = EPD && (k0 + 4 * fc) >= H;              // second half of the features: x_m - y_m
+        const float4 f = diff ? make_float4(xreg.x - yreg.x, xreg.y - yreg.y, xreg.z - yreg.z, xreg.w - yreg.w)
+                              : make_float4(xreg.x * yreg.x, xreg.y * yreg.y, xreg.z * yreg.z, xreg.w * yreg.w);
         if (BWD) {
             const int64_t r = row0 + fe;
             const int kk = k0 + 4 * fc;
-            if (r < a.n && (EXACT || kk < H)) *reinterpret_cast<float4*>(a.feat + r * H + kk) = f;
+            if (r < a.n && (EXACT || kk < KT)) *reinterpret_cast<float4*>(a.feat + r * KT + kk) = f;
         }
         Ft_s[(4 * fc + 0) * kBM + fe] = f.x;
         Ft_s[(4 * fc + 1) * kBM + fe] = f.y;
@@ -186,8 +229,8 @@ __global__ void __launch_bounds__(kT, 3) edge_score_kernel(ScoreArgs a) {
     __syncthreads();
     int cur = 0;
 #pragma unroll 1
-    for (int k0 = 0; k0 < H; k0 += kBK) {
-        const bool more = k0 + kBK < H;
+    for (int k0 = 0; k0 < KT; k0 += kBK) {
+        const bool more = k0 + kBK < KT;
         if (more) fetch(k0 + kBK);                 // global loads in flight during the MFMAs
         lds_operands(cur, 0, 0);
 #pragma unroll
@@ -218,8 +261,9 @@ __global__ void __launch_bounds__(kT, 3) edge_score_kernel(ScoreArgs a) {
         for (int g = 0; g < 4; ++g) {
             const int hb = hh * (HP / 2) + 32 * t + 8 * g + 4 * kh;
             if (EXACT || hb < H) {
-                const float4 us = *reinterpret_cast<const float4*>(Us + hb);
-                const float4 ud = *reinterpret_cast<const float4*>(Ud + hb);
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 us = EPD ? z4 : *reinterpret_cast<const float4*>(Us + hb);          // EPD: no node-level term
+                const float4 ud = EPD ? z4 : *reinterpret_cast<const float4*>(Ud + hb);
                 const float4 bb = *reinterpret_cast<const float4*>(a.b1 + hb);
                 const float4 ww = *reinterpret_cast<const float4*>(a.w2 + hb);
                 const float u4[4] = {us.x - ud.x, us.y - ud.y, us.z - ud.z, us.w - ud.w};
@@ -1637,9 +1681,67 @@ __global__ void __launch_bounds__(64 * NW) scorer_bwd_reduce(const float* __rest
     }
 }
 
+// Endpoint reductions of the endpoint-dropout scorer (EdgeProbMLP with dropout): with x_m = A[s] * kx / (1 - p), y_m = A[d] * ky / (1 - p) and
+// dfeat2 [n, 2H] = [d (x_m * y_m) | d (x_m - y_m)],
+//   d A[v, :] = sum_{e in out-row v} (dfa[e] * y_m(e) + dfb[e]) * kx(e) / (1 - p)  +  sum_{e in in-row v} (dfa[e] * x_m(e) - dfb[e]) * ky(e) / (1 - p)
+// (masks recomputed from the hash: row = ORIGINAL edge id, active[r] of row r).  One 4-wave workgroup per node, fixed summation order.
+__global__ void __launch_bounds__(256) epd_endpoint_reduce(const float* __restrict__ dfeat2, const float* __restrict__ A, int64_t N, int64_t H,
+                                                          const int* __restrict__ in_ptr, const int* __restrict__ in_src,
+                                                          const int* __restrict__ in_eid, const int* __restrict__ out_ptr,
+                                                          const int* __restrict__ out_dst, const int* __restrict__ out_eid,
+                                                          const int64_t* __restrict__ active, int64_t row_offset, uint64_t seed_x, uint32_t site_x,
+                                                          uint64_t seed_y, uint32_t site_y, const uint64_t* __restrict__ epoch, uint32_t thresh,
+                                                          float scale, int use_drop, float* __restrict__ dA) {
+    constexpr int NW = 4;
+    __shared__ float part[NW][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t v = blockIdx.x;
+    const int ob = out_ptr[v], no = out_ptr[v + 1] - ob;
+    const int ib = in_ptr[v], ni = in_ptr[v + 1] - ib;
+    const int total = no + ni;
+    const uint64_t sx = fold_epoch(seed_x, epoch), sy = fold_epoch(seed_y, epoch);
+    for (int64_t cbase = 0; cbase < H; cbase += 256) {
+        const int64_t c0 = cbase + static_cast<int64_t>(lane) * 4;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c0 < H) {
+            for (int k = wave; k < total; k += NW) {
+                const bool isout = k < no;
+                const int idx = isout ? ob + k : ib + (k - no);
+                const int r = (isout ? out_eid : in_eid)[idx];
+                const int o = (isout ? out_dst : in_src)[idx];
+                const int64_t e = row_offset + (active ? active[r] : static_cast<int64_t>(r));
+                const float4 fa = *reinterpret_cast<const float4*>(dfeat2 + static_cast<int64_t>(r) * 2 * H + c0);
+                const float4 fb = *reinterpret_cast<const float4*>(dfeat2 + static_cast<int64_t>(r) * 2 * H + H + c0);
+                const float4 ao = *reinterpret_cast<const float4*>(A + static_cast<int64_t>(o) * H + c0);
+                float ko[4] = {1.f, 1.f, 1.f, 1.f}, km[4] = {1.f, 1.f, 1.f, 1.f};    // masks (x scale) of the OTHER endpoint and of this one
+                if (use_drop) {
+                    const uint32_t rx = dropout_row_key(sx, site_x, static_cast<uint64_t>(e)), ry = dropout_row_key(sy, site_y, static_cast<uint64_t>(e));
+                    const uint32_t rmine = isout ? rx : ry, rother = isout ? ry : rx;
+                    const uint32_t m0 = dropout_pair_bits(rmine, static_cast<uint32_t>(c0 >> 1)), m1 = dropout_pair_bits(rmine, static_cast<uint32_t>((c0 >> 1) + 1));
+                    const uint32_t o0 = dropout_pair_bits(rother, static_cast<uint32_t>(c0 >> 1)), o1 = dropout_pair_bits(rother, static_cast<uint32_t>((c0 >> 1) + 1));
+                    km[0] = (m0 & 0xFFFFu) >= thresh ? scale : 0.f; km[1] = (m0 >> 16) >= thresh ? scale : 0.f;
+                    km[2] = (m1 & 0xFFFFu) >= thresh ? scale : 0.f; km[3] = (m1 >> 16) >= thresh ? scale : 0.f;
+                    ko[0] = (o0 & 0xFFFFu) >= thresh ? scale : 0.f; ko[1] = (o0 >> 16) >= thresh ? scale : 0.f;
+                    ko[2] = (o1 & 0xFFFFu) >= thresh ? scale : 0.f; ko[3] = (o1 >> 16) >= thresh ? scale : 0.f;
+                }
+                const float fav[4] = {fa.x, fa.y, fa.z, fa.w}, fbv[4] = {fb.x, fb.y, fb.z, fb.w}, aov[4] = {ao.x, ao.y, ao.z, ao.w};
+                const float sg = isout ? 1.f : -1.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += (fav[j] * (aov[j] * ko[j]) + sg * fbv[j]) * km[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[wave][lane * 4 + j] = acc[j];
+        __syncthreads();
+        const int tt = threadIdx.x;
+        if (cbase + tt < H) dA[v * H + cbase + tt] = (part[0][tt] + part[1][tt]) + (part[2][tt] + part[3][tt]);
+        __syncthreads();
+    }
+}
+
 inline size_t score_smem_bytes(int NT) { return 2 * (static_cast<size_t>(kBK) * 32 * NT * 4 + kBK * kBM * 4) + 2 * kBM * 4 + 2 * kBM * 4; }
 
-template <bool BWD>
+template <bool BWD, bool EPD = false>
 int launch_score(const ScoreArgs& a, hipStream_t stream) {
     const int H = a.H;
     const int NT = H <= 64 ? 2 : H <= 128 ? 4 : 8;     // hidden units padded to 64 / 128 / 256
@@ -1653,11 +1755,11 @@ int launch_score(const ScoreArgs& a, hipStream_t stream) {
     do {                                                                                                            \
         static bool raised = false;                                                                                 \
         if (!raised) {                                                                                              \
-            SGS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_score_kernel<NT_, BWD, EX_>),        \
+            SGS_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_score_kernel<NT_, BWD, EX_, EPD>),   \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sm)));      \
             raised = true;                                                                                          \
         }                                                                                                           \
-        hipLaunchKernelGGL((edge_score_kernel<NT_, BWD, EX_>), grid, blk, sm, stream, a);                           \
+        hipLaunchKernelGGL((edge_score_kernel<NT_, BWD, EX_, EPD>), grid, blk, sm, stream, a);                      \
     } while (0)
     switch (NT) {
         case 2: if (exact) SGS_SCORE_CASE(2, true); else SGS_SCORE_CASE(2, false); break;
@@ -2199,6 +2301,74 @@ int sgs_endpoint_reduce_pair_bits(const float* dfeat, const uint32_t* dvbits, co
     else
         hipLaunchKernelGGL((endpoint_reduce_pair_rowblock<4, true>), grid, dim3(256), 0, stream, dfeat, nodv, codes, N, H, in_ptr, in_src, in_eid,
                            out_ptr, out_dst, out_eid, out_codes, out_U, dvbits, dz, w2, scale, out_U_raw);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+/* ---- endpoint-dropout scorer (EdgeProbMLP with dropout > 0, model.py:16-45): see the EPD notes at edge_score_kernel ---- */
+size_t sgs_edge_score_epd_workspace_bytes(int64_t H) { return carve_bytes(2 * static_cast<size_t>(H < 0 ? 0 : H) * (H < 0 ? 0 : H), 4) + 256; }
+
+static int epd_args(ScoreArgs& a, const char* who, const float* A, int64_t N, int64_t H, const int64_t* edge_index, int64_t E, int64_t edge_id_offset,
+                    const float* W1, const float* b1, const float* w2, const float* b2, float p_hidden, uint64_t seed, uint32_t site, float p_ep,
+                    uint64_t seed_x, uint32_t site_x, uint64_t seed_y, uint32_t site_y, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (int rc = check_common(who, N, H, E, p_hidden)) return rc;
+    SGS_REQUIRE(H % 16 == 0, SGS_EINVAL, "%s: the endpoint-dropout scorer needs H %% 16 == 0 (H=%lld)", who, (long long)H);
+    SGS_REQUIRE(p_ep >= 0.f && p_ep < 1.f, SGS_EINVAL, "%s: bad endpoint dropout probability", who);
+    SGS_REQUIRE(A && edge_index && W1 && b1 && w2 && b2, SGS_EINVAL, "%s: null pointer", who);
+    SGS_REQUIRE(ws && ws_bytes >= sgs_edge_score_epd_workspace_bytes(H), SGS_EWORKSPACE, "%s: workspace too small", who);
+    Carver cv(ws);
+    float* WT = cv.take<float>(2 * static_cast<size_t>(H) * H);
+    hipLaunchKernelGGL(transpose_w1_full, dim3(cdiv(2 * H, 32), cdiv(H, 32)), dim3(kT), 0, stream, W1, static_cast<int>(H), WT);
+    a.codes = A; a.U = nullptr; a.src = edge_index; a.dst = edge_index + E; a.H = static_cast<int>(H); a.row_offset = edge_id_offset;
+    a.WaT = WT; a.b1 = b1; a.w2 = w2; a.b2 = b2;
+    a.drop_scale = 1.0f / (1.0f - p_hidden); a.drop_thresh = dropout_thresh(p_hidden); a.seed = seed; a.epoch = epoch_ptr(); a.site = site;
+    a.use_drop = p_hidden > 0.f;
+    a.epd = p_ep > 0.f; a.seed_x = seed_x; a.seed_y = seed_y; a.site_x = site_x; a.site_y = site_y;
+    a.ep_scale = 1.0f / (1.0f - p_ep); a.ep_thresh = dropout_thresh(p_ep);
+    return SGS_OK;
+}
+
+int sgs_edge_score_epd_fwd(const float* A, int64_t N, int64_t H, const int64_t* edge_index, int64_t E, int64_t edge_id_offset, const float* W1,
+                           const float* b1, const float* w2, const float* b2, float p_hidden, uint64_t seed, uint32_t site, float p_ep,
+                           uint64_t seed_x, uint32_t site_x, uint64_t seed_y, uint32_t site_y, float* p_out, void* ws, size_t ws_bytes,
+                           sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (E == 0) return SGS_OK;
+    SGS_REQUIRE(p_out, SGS_EINVAL, "sgs_edge_score_epd_fwd: null pointer");
+    ScoreArgs a{};
+    if (int rc = epd_args(a, "sgs_edge_score_epd_fwd", A, N, H, edge_index, E, edge_id_offset, W1, b1, w2, b2, p_hidden, seed, site, p_ep, seed_x, site_x,
+                          seed_y, site_y, ws, ws_bytes, stream)) return rc;
+    a.active = nullptr; a.n = E; a.p_out = p_out;
+    return launch_score<false, true>(a, stream);
+}
+
+int sgs_edge_score_epd_bwd_core(const float* A, int64_t N, int64_t H, const int64_t* edge_index, int64_t E, int64_t edge_id_offset,
+                                const int64_t* active_eid, int64_t n_active, const float* grad_p, const float* W1, const float* b1, const float* w2,
+                                const float* b2, float p_hidden, uint64_t seed, uint32_t site, float p_ep, uint64_t seed_x, uint32_t site_x,
+                                uint64_t seed_y, uint32_t site_y, float* dv, float* hdz_part, float* dz, float* feat2, void* ws, size_t ws_bytes,
+                                sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(n_active >= 0 && (active_eid || n_active == E), SGS_EINVAL, "sgs_edge_score_epd_bwd_core: n_active must equal E when active_eid is NULL");
+    if (n_active == 0) return SGS_OK;
+    SGS_REQUIRE(grad_p && dv && hdz_part && dz && feat2, SGS_EINVAL, "sgs_edge_score_epd_bwd_core: null pointer");
+    ScoreArgs a{};
+    if (int rc = epd_args(a, "sgs_edge_score_epd_bwd_core", A, N, H, edge_index, E, edge_id_offset, W1, b1, w2, b2, p_hidden, seed, site, p_ep, seed_x,
+                          site_x, seed_y, site_y, ws, ws_bytes, stream)) return rc;
+    a.active = active_eid; a.n = n_active; a.gp = grad_p; a.dv = dv; a.hdz = hdz_part; a.dz = dz; a.feat = feat2;
+    return launch_score<true, true>(a, stream);
+}
+
+int sgs_edge_score_epd_reduce(const float* dfeat2, const float* A, int64_t N, int64_t H, const int32_t* in_ptr, const int32_t* in_src,
+                              const int32_t* in_eid, const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
+                              const int64_t* active_eid, int64_t edge_id_offset, float p_ep, uint64_t seed_x, uint32_t site_x, uint64_t seed_y,
+                              uint32_t site_y, float* dA, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && H > 0 && H % 4 == 0 && N < (int64_t(1) << 31) && p_ep >= 0.f && p_ep < 1.f, SGS_EINVAL, "sgs_edge_score_epd_reduce: bad arguments");
+    if (N == 0) return SGS_OK;
+    SGS_REQUIRE(dfeat2 && A && in_ptr && in_src && in_eid && out_ptr && out_dst && out_eid && dA, SGS_EINVAL, "sgs_edge_score_epd_reduce: null pointer");
+    hipLaunchKernelGGL(epd_endpoint_reduce, dim3(static_cast<unsigned>(N)), dim3(256), 0, stream, dfeat2, A, N, H, in_ptr, in_src, in_eid, out_ptr, out_dst,
+                       out_eid, active_eid, edge_id_offset, seed_x, site_x, seed_y, site_y, epoch_ptr(), dropout_thresh(p_ep), 1.0f / (1.0f - p_ep),
+                       p_ep > 0.f ? 1 : 0, dA);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

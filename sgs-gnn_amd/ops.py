@@ -906,6 +906,81 @@ def edge_score(codes, fc1_w, fc1_b, fc2_w, fc2_b, edge_index, active=None, p=0.0
                             edge_index.contiguous(), active, float(p), int(seed), int(site), int(edge_id_offset), pairs)
 
 
+class _EdgeScoreEPD(torch.autograd.Function):
+    """EdgeProbMLP with dropout > 0 (model.py:16-45): `_edge_score(drop(A[src]), drop(A[dst]))` with the two endpoint masks drawn per (edge,
+    endpoint), straight from the node table A = relu(fcdim(X)) [N, H] and the scored edge list -- no [E', H] gathers, masks or
+    concatenations on the way (include/sgs_hip.h, "Endpoint-dropout scorer").  The backward runs over the active rows only (the trainer's
+    ActiveSet: the q sampled edges in the hybrid pipeline) and materialises the features of THOSE rows alone."""
+
+    @staticmethod
+    def forward(ctx, A, W1, b1, w2, b2, edge_index, active, p, seed, site, p_ep, seed_x, site_x, seed_y, site_y, edge_id_offset):
+        L = _lib.lib()
+        N, H = A.shape
+        E = edge_index.shape[1]
+        out = torch.empty(E, dtype=torch.float32, device=A.device)
+        ws = workspace(L.sgs_edge_score_epd_workspace_bytes(H), A.device)
+        _lib.check(L.sgs_edge_score_epd_fwd(_ptr(A, torch.float32), N, H, _ptr(edge_index, torch.int64), E, edge_id_offset, _ptr(W1, torch.float32),
+                                            _ptr(b1), _ptr(w2), _ptr(b2), float(p), seed, site, float(p_ep), seed_x, site_x, seed_y, site_y, _ptr(out),
+                                            ws.data_ptr(), ws.numel(), _stream()), "sgs_edge_score_epd_fwd")
+        ctx.save_for_backward(A, W1, b1, w2, b2, edge_index)
+        ctx.active, ctx.cfg = active, (float(p), seed, site, float(p_ep), seed_x, site_x, seed_y, site_y, edge_id_offset)
+        return out
+
+    @staticmethod
+    def backward(ctx, gp):
+        L = _lib.lib()
+        A, W1, b1, w2, b2, edge_index = ctx.saved_tensors
+        p, seed, site, p_ep, seed_x, site_x, seed_y, site_y, offset = ctx.cfg
+        N, H = A.shape
+        E = edge_index.shape[1]
+        dev = A.device
+        act = ctx.active
+        if act is not None and act.eid is not None:
+            eid, graph = act.eid, act.graph
+            n = eid.numel()
+            tok = _zero_token(dev)
+            if act.gq is not None and gp.numel() == E and gp.stride(0) == 0 and gp.data_ptr() == tok.data_ptr():
+                gp_act = act.gq
+            else:
+                gp_act = gp.index_select(0, eid)
+                if act.gq is not None:
+                    gp_act = gp_act + act.gq
+            act.gq = None
+        else:
+            eid, graph, n = None, get_graph(edge_index, N), E
+            gp_act = gp.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        dv, feat2, dz = torch.empty(n, H, **f32), torch.empty(n, 2 * H, **f32), torch.empty(n, **f32)
+        tile = L.sgs_edge_score_bwd_tile()
+        hdz = torch.empty((n + tile - 1) // tile, H, **f32)
+        dA = torch.zeros(N, H, **f32) if n == 0 else torch.empty(N, H, **f32)
+        dW1 = torch.zeros_like(W1) if n == 0 else torch.empty_like(W1)
+        if n == 0:
+            return dA, dW1, torch.zeros(H, **f32), torch.zeros(H, **f32), torch.zeros(1, **f32), *([None] * 11)
+        ws = workspace(L.sgs_edge_score_epd_workspace_bytes(H), dev)
+        _lib.check(L.sgs_edge_score_epd_bwd_core(_ptr(A), N, H, _ptr(edge_index), E, offset, _ptr(eid), n, _ptr(gp_act), _ptr(W1), _ptr(b1), _ptr(w2),
+                                                 _ptr(b2), p, seed, site, p_ep, seed_x, site_x, seed_y, site_y, _ptr(dv), _ptr(hdz), _ptr(dz), _ptr(feat2),
+                                                 ws.data_ptr(), ws.numel(), _stream()), "sgs_edge_score_epd_bwd_core")
+        wsg = workspace(L.sgs_gemm_tn_workspace_bytes(n, H, 2 * H), dev)
+        _lib.check(L.sgs_gemm_tn(_ptr(dv), _ptr(feat2), n, H, 2 * H, _ptr(dW1), wsg.data_ptr(), wsg.numel(), _stream()), "sgs_gemm_tn")
+        db1, dw2 = _colsum(dv), _colsum(hdz)
+        db2 = _colsum(dz.view(n, 1)).reshape(1)
+        dfeat2 = torch.mm(dv, W1)                               # [n, 2H] = [d (x_m * y_m) | d (x_m - y_m)]  (library GEMM)
+        _lib.check(L.sgs_edge_score_epd_reduce(_ptr(dfeat2), _ptr(A), N, H, _ptr(graph.in_ptr), _ptr(graph.in_src), _ptr(graph.in_eid), _ptr(graph.out_ptr),
+                                               _ptr(graph.out_dst), _ptr(graph.out_eid), _ptr(eid), offset, p_ep, seed_x, site_x, seed_y, site_y, _ptr(dA),
+                                               _stream()), "sgs_edge_score_epd_reduce")
+        return dA, dW1, db1, dw2, db2, *([None] * 11)
+
+
+def edge_score_epd(A, fc1_w, fc1_b, fc2_w, fc2_b, edge_index, active=None, p=0.0, seed=0, site=0, p_ep=0.0, seed_x=0, site_x=0, seed_y=0,
+                   site_y=0, edge_id_offset=0):
+    """The scorer of EdgeProbMLP when its endpoint dropout is on (see _EdgeScoreEPD): A [N,H] = relu(fcdim(X)); -> p [E]."""
+    _need_gpu(A, fc1_w, edge_index)
+    return _EdgeScoreEPD.apply(A.contiguous(), fc1_w.contiguous(), fc1_b.contiguous(), fc2_w.reshape(-1).contiguous(), fc2_b.contiguous(),
+                               edge_index.contiguous(), active, float(p), int(seed), int(site), float(p_ep), int(seed_x), int(site_x), int(seed_y),
+                               int(site_y), int(edge_id_offset))
+
+
 # ------------------------------------------------------------------ gate + losses (K6)
 def _u8(mask: torch.Tensor) -> torch.Tensor:
     if mask.dtype == torch.bool:

@@ -64,18 +64,15 @@ class EdgeProbMLP(nn.Module):
             prob = ops.edge_score(A, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, g,
                                   active=self.last_active)
         else:
-            Eg, H = g.shape[1], A.shape[1]
+            # per-(edge, endpoint) dropout (model.py:21-25) inside the scorer kernels: masks are hashed from (seed, site, edge, column),
+            # nothing of size [E', H] is gathered, masked or concatenated (include/sgs_hip.h, "Endpoint-dropout scorer")
             sx, sy, ss = _DropoutClock.next_seed(), _DropoutClock.next_seed(), _DropoutClock.next_seed()
-            kx = ops.dropout_keep(sx, SITE_MLP_X, Eg, H, p, A.device)
-            ky = ops.dropout_keep(sy, SITE_MLP_Y, Eg, H, p, A.device)
-            table = torch.cat([A[g[0]] * kx / (1 - p), A[g[1]] * ky / (1 - p)], dim=0)      # [2E',H] endpoint codes
-            ar = torch.arange(Eg, device=A.device)
-            pair = torch.stack([ar, ar + Eg])
-            # the scored object is the pseudo-graph `pair` over the 2E' table rows, not the batch graph: the trainer's active set
-            # (edge ids / CSR of the batch graph) does not apply to it, so the backward runs densely over `pair` with its own CSR
-            self.last_active = None
-            prob = ops.edge_score(table, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, pair,
-                                  active=None, p=p, seed=ss, site=SITE_SCORE)
+            if g is not edge_index:
+                self.last_active = None        # scores of the RANDOM edges: the trainer's active set (ids of the batch graph) does not apply
+            if A.shape[1] % 16 != 0:
+                raise NotImplementedError("EdgeProbMLP with dropout needs hidden_dim % 16 == 0")
+            prob = ops.edge_score_epd(A, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, g, active=self.last_active,
+                                      p=p, seed=ss, site=SITE_SCORE, p_ep=p, seed_x=sx, site_x=SITE_MLP_X, seed_y=sy, site_y=SITE_MLP_Y)
         return prob.unsqueeze(1)
 
 

@@ -485,3 +485,41 @@ def test_fused_dfeat_entry_point_by_source_partials_and_G(ops, H, p, n):
                                                    ur2.data_ptr(), st), "reduce_fused")
     torch.cuda.synchronize()
     assert _rel(oc2, oc1.cpu()) < 3e-6 and _rel(ou2, ou1.cpu()) < 3e-6 and _rel(ur2, ur1.cpu()) < 3e-6
+
+
+@pytest.mark.parametrize("N,H,E,q,p", [(500, 256, 70_001, 20_000, 0.3), (300, 64, 9_000, None, 0.3), (400, 128, 66_000, 66_000, 0.5), (200, 32, 3000, 500, 0.0)])
+def test_endpoint_dropout_scorer_vs_fp64_oracle(ops, N, H, E, q, p):
+    """EdgeProbMLP's scorer with per-(edge, endpoint) dropout inside the kernels (ops.edge_score_epd: sgs_edge_score_epd_fwd / _bwd_core /
+    _reduce) against the fp64 oracle fed the SAME masks (sgs_dropout_keep): forward for every edge, backward over an active subset
+    (q rows; None = dense over all E) -- d A, d fc1.weight (both halves), d fc1.bias, d fc2.weight, d fc2.bias."""
+    from sgs_gnn_amd.model import SITE_MLP_X, SITE_MLP_Y, SITE_SCORE
+    codes, ei, W1, b1, W2, b2, g = _case(N, H, E, 200 + H)
+    sx, sy, ss = 11, 12, 13
+    if p > 0:
+        kx, ky, kh = (ops.dropout_keep(sd, site, E, H, p, DEV).cpu() for sd, site in ((sx, SITE_MLP_X), (sy, SITE_MLP_Y), (ss, SITE_SCORE)))
+    else:
+        kx = ky = torch.ones(E, H, dtype=torch.bool)
+        kh = None
+    Ao = codes.clone().double().requires_grad_(True)
+    Po = [t.clone().double().requires_grad_(True) for t in (W1, b1, W2, b2)]
+    xm = Ao[ei[0]] * kx / (1 - p)
+    ym = Ao[ei[1]] * ky / (1 - p)
+    po = O.edge_score(xm, ym, Po[0], Po[1], Po[2], Po[3], p, kh).squeeze(1)
+    dl = [t.clone().to(DEV).requires_grad_(True) for t in (codes, W1, b1, W2, b2)]
+    act = ops.ActiveSet() if q is not None else None
+    ei_d = ei.to(DEV)
+    pd = ops.edge_score_epd(dl[0], dl[1], dl[2], dl[3], dl[4], ei_d, active=act, p=p, seed=ss, site=SITE_SCORE, p_ep=p, seed_x=sx,
+                            site_x=SITE_MLP_X, seed_y=sy, site_y=SITE_MLP_Y)
+    assert float((pd.detach().cpu().double() - po.detach()).abs().max()) < 2e-6
+    gp = torch.zeros(E)
+    if q is not None:
+        eid = torch.sort(torch.randperm(E, generator=g)[:q]).values
+        gp[eid] = torch.randn(q, generator=g)
+        act.set(eid.to(DEV), ops.Graph(ei[:, eid].to(DEV), N))
+    else:
+        gp = torch.randn(E, generator=g)
+    po.backward(gp.double())
+    pd.backward(gp.to(DEV))
+    for name, a, b in zip(["dA", "dW1", "db1", "dW2", "db2"], [t.grad for t in dl], [Ao.grad, Po[0].grad, Po[1].grad, Po[2].grad, Po[3].grad]):
+        assert bool(torch.isfinite(a).all()), name
+        assert _rel(a, b.reshape(a.shape)) < 2e-5, (name, _rel(a, b.reshape(a.shape)))
