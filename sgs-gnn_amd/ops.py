@@ -1352,6 +1352,78 @@ def er_prior(edge_index: torch.Tensor, num_nodes: int, seed: int = 0, walk_lengt
     return w if raw else torch.softmax(w * E ** -0.5, dim=0)
 
 
+# ------------------------------------------------------------------ sparse node features (CitationFull-Cora: bag-of-words rows, 0.7 % dense)
+class FeatCSR:
+    """CSR of a sparse feature matrix x [N, F] and of its transpose, built once per graph: the node-level products of the first GCN
+    layers, x W^T and d W = d Y^T x, are then two SpMMs over nnz(x) instead of two dense [N, F] x [F, H] GEMMs (model.py:159 feeds the
+    raw bag-of-words rows to GCNConv.lin: 88 GFLOP per product at CitationFull-Cora's size, 0.6 GFLOP of it on non-zeros)."""
+    __slots__ = ("N", "F", "nnz", "ptr", "col", "val", "tptr", "trow", "tval")
+
+
+_FEAT_SPARSE_MAX_DENSITY = 0.05        # above this the library GEMM wins
+_FEAT_SPARSE_MIN_ELEMS = 1 << 22       # small matrices: not worth a second code path
+
+
+def feature_csr(x: torch.Tensor, build: bool = True):
+    """FeatCSR of `x` if it is sparse enough (cached on the tensor, keyed by its version), else None.  Building reads the non-zero count
+    back (set-up work, once per graph); inside a stream capture only an existing cache entry is used."""
+    c = getattr(x, "_sgs_fcsr", None)
+    if c is not None and c[1] == x._version:
+        return c[0]
+    if not build or not x.is_cuda or x.dim() != 2 or x.dtype != torch.float32 or x.numel() < _FEAT_SPARSE_MIN_ELEMS or x.requires_grad:
+        return None
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    N, F_ = x.shape
+    nz = x != 0
+    nnz = int(nz.sum())
+    fc = None
+    if nnz <= _FEAT_SPARSE_MAX_DENSITY * x.numel() and nnz < 2**31:
+        fc = FeatCSR()
+        idx = torch.nonzero(nz)                                    # row-major: sorted by (row, col)
+        rows, cols = idx[:, 0], idx[:, 1]
+        val = x[rows, cols].contiguous()
+        i32 = dict(dtype=torch.int32, device=x.device)
+        fc.N, fc.F, fc.nnz = N, F_, nnz
+        fc.ptr = torch.zeros(N + 1, **i32)
+        fc.ptr[1:] = torch.cumsum(torch.bincount(rows, minlength=N), 0).to(torch.int32)
+        fc.col, fc.val = cols.to(torch.int32).contiguous(), val
+        order = torch.argsort(cols, stable=True)                   # the transpose: sorted by (col, row)
+        fc.tptr = torch.zeros(F_ + 1, **i32)
+        fc.tptr[1:] = torch.cumsum(torch.bincount(cols, minlength=F_), 0).to(torch.int32)
+        fc.trow, fc.tval = rows[order].to(torch.int32).contiguous(), val[order].contiguous()
+    try:
+        x._sgs_fcsr = (fc, x._version)
+    except Exception:
+        pass
+    return fc
+
+
+def _x_wt(x, W):
+    """x W^T: over the non-zeros of x when it has a FeatCSR (gathering rows of W^T), else the library GEMM."""
+    fc = feature_csr(x)
+    if fc is None:
+        return x @ W.t()
+    Wt = W.t().contiguous()                                        # [F, H]
+    return _spmm(Wt, fc.ptr, fc.col, fc.val, None, None, ACT_NONE, 0.0, 0, 0, fc.N, W.shape[0], fc.nnz)
+
+
+def _dyt_x(dY, x, W_shape):
+    """d W [M, F] = d Y^T x: over the non-zeros of x^T when x has a FeatCSR, else sgs_gemm_tn."""
+    L = _lib.lib()
+    fc = feature_csr(x)
+    M, Nn = W_shape
+    if fc is not None:
+        dWt = _spmm(dY.contiguous(), fc.tptr, fc.trow, fc.tval, None, None, ACT_NONE, 0.0, 0, 0, fc.F, M, fc.nnz)      # [F, M]
+        return dWt.t().contiguous()
+    K = x.shape[0]
+    dW = torch.empty(M, Nn, dtype=torch.float32, device=x.device)
+    ws = workspace(L.sgs_gemm_tn_workspace_bytes(K, M, Nn), x.device)
+    _lib.check(L.sgs_gemm_tn(_ptr(dY, torch.float32), _ptr(x.contiguous(), torch.float32), K, M, Nn, _ptr(dW), ws.data_ptr(), ws.numel(), _stream()),
+               "sgs_gemm_tn")
+    return dW
+
+
 # ------------------------------------------------------------------ one GCN layer as ONE autograd node
 class _GCNLayer(torch.autograd.Function):
     """Y = act(A_hat (x W^T) + bias): the node-level product (library GEMM) and the propagation (K5) in a single
@@ -1362,7 +1434,7 @@ class _GCNLayer(torch.autograd.Function):
     def forward(ctx, x, W, handle, bias, nm, act, p, seed, site, xl):
         gr = nm.graph
         if xl is None:
-            xl = x @ W.t()
+            xl = _x_wt(x, W)
         N, D = xl.shape
         Y = _spmm(xl, gr.in_ptr, gr.in_src, nm.what_in, nm.what_loop, bias, act, p, seed, site, N, D, gr.n_edges)
         ctx.nm, ctx.act, ctx.p = nm, act, p
@@ -1392,11 +1464,7 @@ class _GCNLayer(torch.autograd.Function):
         if need_x or need_W:
             dxl = _spmm(dZ, gr.out_ptr, gr.out_dst, nm.what_out, nm.what_loop, None, ACT_NONE, 0.0, 0, 0, N, D, gr.n_edges)
             if need_W:
-                K, M, Nn = x.shape[0], W.shape[0], W.shape[1]
-                dW = torch.empty(M, Nn, dtype=torch.float32, device=x.device)
-                ws = workspace(L.sgs_gemm_tn_workspace_bytes(K, M, Nn), x.device)
-                _lib.check(L.sgs_gemm_tn(_ptr(dxl), _ptr(x.contiguous(), torch.float32), K, M, Nn, _ptr(dW), ws.data_ptr(), ws.numel(),
-                                         _stream()), "sgs_gemm_tn")
+                dW = _dyt_x(dxl, x, W.shape)
             if need_x:
                 dx = dxl @ W
         if ctx.has_handle and ctx.needs_input_grad[2]:

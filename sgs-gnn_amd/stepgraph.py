@@ -193,6 +193,9 @@ class StepGraphs:
         # the fused scorer backward (ops._edge_score_backward_fused) needs edge lists sorted by source; a capture bakes the choice in, so
         # the slots' static edge_index carries the flag and a partition that is not sorted drops the captures made under it (forward())
         self.src_sorted = True
+        # sparse node features (ops.FeatCSR; CitationFull-Cora's bag-of-words rows): when EVERY partition of the loader has one, the slots carry
+        # static CSR buffers of this capacity, filled by the staging copy, and the captured first-layer products run over the non-zeros
+        self.fcsr_cap = 0
         self.capture_seconds = 0.0
         self.captures = 0
         self.debug_keep = False                         # tests: keep static views of a replay's draws / outputs per slot
@@ -249,6 +252,7 @@ class StepGraphs:
         if batches is None:
             return
         n, e = self.npad, dict(self.ecap)
+        fcap, fall = 0, True
         for b in batches:
             if b is None or not hasattr(b, "edge_index"):
                 continue
@@ -258,7 +262,12 @@ class StepGraphs:
             if b.x.is_cuda and E > self.q and self.src_sorted and not ops.src_sorted(b.edge_index):
                 self.src_sorted = False                 # settled before the first capture (see forward())
             if b.x.is_cuda and E > 0:
-                self._sources(b, want_norm=E <= self.q, want_pairs=E > self.q and self.pairs_ok)   # CSR (+ unit norm / mates) of every resident partition, once
+                src = self._sources(b, want_norm=E <= self.q, want_pairs=E > self.q and self.pairs_ok)   # CSR (+ unit norm / mates) of every resident partition, once
+                fc = src["fcsr"]
+                fall = fall and fc is not None
+                fcap = max(fcap, fc.nnz if fc is not None else 0)
+        if fall and fcap > 0 and not any(self.slots.values()):
+            self.fcsr_cap = max(self.fcsr_cap, _round_up(fcap, 1024))
         self._set_capacity(n, e)
 
     def _set_capacity(self, n, e) -> None:
@@ -275,6 +284,13 @@ class StepGraphs:
         E = int(batch.edge_index.shape[1])
         return int(batch.x.shape[0]) <= self.npad and 0 < E <= self.ecap[E > self.q] and (self.nfeat in (None, int(batch.x.shape[1])))
 
+    def _fcsr_ok(self, batch) -> bool:
+        """Does the partition fit the slots' static feature-CSR buffers (trivially true when the slots carry none)?"""
+        if not self.fcsr_cap:
+            return True
+        fc = ops.feature_csr(batch.x)
+        return fc is not None and fc.nnz <= self.fcsr_cap
+
     # ------------------------------------------------------------------ slots and staging
     def _new_slot(self, sampled: bool, index: int, like) -> _Slot:
         dev, N, Ecap = self.device, self.npad, self.ecap[sampled]
@@ -286,6 +302,15 @@ class StepGraphs:
         s.sampled, s.index, s.npad, s.ecap = sampled, index, N, Ecap
         z = dict(device=dev)
         x = torch.zeros(N, F, dtype=torch.float32, **z)
+        fcs = None
+        if self.fcsr_cap:
+            fcs = ops.FeatCSR()
+            fcs.N, fcs.F, fcs.nnz = N, F, self.fcsr_cap
+            i32 = dict(dtype=torch.int32, device=dev)
+            fcs.ptr, fcs.tptr = torch.zeros(N + 1, **i32), torch.zeros(F + 1, **i32)
+            fcs.col, fcs.trow = torch.zeros(self.fcsr_cap, **i32), torch.zeros(self.fcsr_cap, **i32)
+            fcs.val, fcs.tval = torch.zeros(self.fcsr_cap, dtype=torch.float32, **z), torch.zeros(self.fcsr_cap, dtype=torch.float32, **z)
+        x._sgs_fcsr = (fcs, x._version)                 # (None: the slot's x is never scanned for sparsity -- its content changes per partition)
         y = torch.zeros(N, dtype=torch.int64, **z)
         s.mask4 = torch.zeros(_round_up(N, 4), dtype=torch.uint8, **z)
         tm = s.mask4[:N].view(torch.bool)
@@ -336,7 +361,7 @@ class StepGraphs:
             m4 = torch.zeros(_round_up(N, 4), dtype=torch.uint8, device=batch.x.device)
             m4[:N] = ops._u8(batch.train_mask)
             src = dict(graph=g, mask4=m4, x=batch.x.contiguous(), y=batch.y.contiguous(), norm=ops.gcn_norm(g, None) if want_norm else None,
-                       pairs=ops.get_pairs(batch.edge_index, N, build=True) if want_pairs else None)
+                       pairs=ops.get_pairs(batch.edge_index, N, build=True) if want_pairs else None, fcsr=ops.feature_csr(batch.x))
             try:
                 batch._sgs_stage_src = src
             except Exception:
@@ -381,6 +406,13 @@ class StepGraphs:
             segs += [(nm.what_in, sn.what_in, E * 4, E * 4, 0),
                      (nm.what_out, sn.what_out, E * 4, E * 4, 0),
                      (nm.what_loop, sn.what_loop, N * 4, Np * 4, 0x3F800000)]        # an isolated padded node: deg 1, loop weight 1.0f
+        if self.fcsr_cap:
+            fc, fs = src["fcsr"], sb.x._sgs_fcsr[0]
+            if fc is None or fc.nnz > self.fcsr_cap:
+                raise RuntimeError("sgs_gnn_amd: partition does not fit the slots' sparse-feature buffers")     # (forward() re-captures before this)
+            nz = fc.nnz
+            segs += [(fc.ptr, fs.ptr, (N + 1) * 4, (Np + 1) * 4, nz), (fc.col, fs.col, nz * 4, nz * 4, 0), (fc.val, fs.val, nz * 4, nz * 4, 0),
+                     (fc.tptr, fs.tptr, (F + 1) * 4, (F + 1) * 4, 0), (fc.trow, fs.trow, nz * 4, nz * 4, 0), (fc.tval, fs.tval, nz * 4, nz * 4, 0)]
         words = []
         keep = []
         for s_, d_, nb_s, nb_d, pad in segs:
@@ -659,6 +691,11 @@ class StepGraphs:
             torch.cuda.synchronize()
             self.src_sorted = False
             self.slots = {True: [], False: []}          # captured for source-sorted partitions: recorded again without the fused backward
+            self.stage_cache.clear()
+        if not self._fcsr_ok(batch):
+            torch.cuda.synchronize()
+            self.fcsr_cap = 0                           # a partition with dense (or more) features: the slots go back to the library GEMM
+            self.slots = {True: [], False: []}
             self.stage_cache.clear()
         if not self._fits(batch):
             E = int(batch.edge_index.shape[1])

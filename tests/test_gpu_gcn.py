@@ -240,3 +240,53 @@ def test_graph_filter_equals_build_of_the_compacted_edges(pkg, N, E, q):
         n = q if name in ("in_src", "in_eid", "out_dst", "out_eid") else a.numel()
         assert torch.equal(a[:n], b[:n]), name
     assert ops.get_graph(r.edge_index, N) is child               # cached on the drawn edge list
+
+
+def test_sparse_feature_products_match_dense_and_replay_through_the_slots():
+    """ops.feature_csr: bag-of-words node features (CitationFull-Cora: 0.7 % dense) run the first layers' x W^T and d W = d Y^T x as SpMMs
+    over nnz(x).  (1) both products against the dense ones; (2) a layer's gradients with the sparse path on and off; (3) graph mode: the
+    CSR of every partition is staged into the slots' static buffers -- two partitions with different nnz replay equal to eager training."""
+    import argparse
+    import sgs_gnn_amd as S
+    ops = S.ops
+    g = torch.Generator(device=DEV).manual_seed(4)
+    N, F_, H = 2100, 2048, 64
+
+    def feats(n, seed):
+        gg = torch.Generator(device=DEV).manual_seed(seed)
+        x = (torch.rand(n, F_, device=DEV, generator=gg) < 0.01).float() * torch.rand(n, F_, device=DEV, generator=gg)
+        return x / x.sum(1, keepdim=True).clamp_min(1e-12)
+    x = feats(N, 1)
+    fc = ops.feature_csr(x)
+    assert fc is not None and fc.nnz == int((x != 0).sum()) and fc.N == N and fc.F == F_
+    W = torch.randn(H, F_, device=DEV, generator=g) * 0.05
+    dY = torch.randn(N, H, device=DEV, generator=g)
+    torch.testing.assert_close(ops._x_wt(x, W), x @ W.t(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ops._dyt_x(dY, x, W.shape), dY.t() @ x, rtol=1e-4, atol=1e-6)
+    dense = torch.randn(N, F_, device=DEV, generator=g)
+    assert ops.feature_csr(dense) is None                               # N(0,1) features (Reddit): the library GEMM
+    # (3) graph mode against eager on two partitions of different sizes / nnz
+    crit = torch.nn.CrossEntropyLoss()
+    bs = []
+    for i, (n, E) in enumerate([(2100, 9000), (2080, 7000)]):
+        b = S.synthetic_graph(n, E, 8, 5, seed=60 + i, device=DEV)
+        b.x = feats(n, 70 + i)
+        bs.append(b)
+
+    def run(hipgraph):
+        torch.manual_seed(0)
+        S.fix_seeds(0)
+        m = S.GNNModel(F_, 32, 5, dropout_prob=0.0, edge_mlp_type="GCN").to(DEV)
+        og = S.FusedAdam([p for nme, p in m.named_parameters() if "gcn" in nme], lr=1e-2)
+        oe = S.FusedAdam([p for nme, p in m.named_parameters() if "edge_prob_mlp" in nme], lr=1e-2)
+        a = argparse.Namespace(device=DEV, mode="learned", pipeline="hybrid", edge_mlp_type="GCN", conditional=True, sparse_edge_mlp=True, t_init=0.7,
+                               t_min=0.5, degree_bias_coef=0.3, reg1=True, reg2=True, regularizer1_coef=1.0, consist_reg_coef=0.5,
+                               hybrid_checkpoint=False, sgs_hipgraph=hipgraph)
+        rets = [S.train(a, ep, 3, m, og, oe, None, crit, bs, q=20_000) for ep in range(3)]       # E <= q: unsampled steps, deterministic
+        return rets, m
+    r_e, m_e = run(False)
+    r_g, m_g = run(True)
+    assert m_g._sgs_stepgraphs.fcsr_cap >= max(ops.feature_csr(b.x).nnz for b in bs)
+    assert r_e == r_g
+    for (k, a_), (_, b_) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
+        assert torch.equal(a_, b_), k
