@@ -554,6 +554,14 @@ int sgs_edge_reg_partial(const float* w, const int64_t* sampled_edge_index, int6
  * per-source sum of g_edge (sgs_spmm_csr over the src-CSR with D = 1) + g_selfloop.
  * sgs_gather_by_eid / sgs_scatter_by_eid re-order per-edge arrays between edge-id and CSR entry order.
  * ---------------------------------------------------------------------------------- */
+/* Node-level attention scores of a GATConv layer in one pass over x' [N, D]: a_src[i] = <x'[i, :], att_src>, a_dst likewise (GATConv's
+ * (x' * att).sum(-1)); backward: dxl (+)= g_src (x) att_src + g_dst (x) att_dst (accumulate != 0: added to dxl), d att_src = sum_i g_src[i] x'[i, :],
+ * d att_dst likewise (fixed summation order).  ws: sgs_gat_scores_bwd_workspace_bytes(N, D). */
+int sgs_gat_scores_fwd(const float* xl, int64_t N, int64_t D, const float* att_src, const float* att_dst, float* a_src, float* a_dst,
+                       sgs_stream_t stream);
+size_t sgs_gat_scores_bwd_workspace_bytes(int64_t N, int64_t D);
+int sgs_gat_scores_bwd(const float* xl, int64_t N, int64_t D, const float* att_src, const float* att_dst, const float* g_src, const float* g_dst,
+                       int accumulate, float* dxl, float* datt_src, float* datt_dst, void* ws, size_t ws_bytes, sgs_stream_t stream);
 int sgs_gat_alpha_fwd(const float* a_src, const float* a_dst, int64_t N, int64_t n_edges, const int32_t* in_ptr,
                       const int32_t* in_src, const int32_t* in_eid, float negative_slope, float p_drop, uint64_t seed,
                       uint32_t site, float* soft_in, float* soft_loop, float* alpha_in, float* alpha_loop,

@@ -136,6 +136,76 @@ __global__ void __launch_bounds__(kT) scatter_by_eid(const float* __restrict__ i
     if (k < n) by_eid[eid[k]] = in_order[k];
 }
 
+// Node-level attention scores a_s = <x', att_src>, a_d = <x', att_dst> in ONE pass over x' (one wave per row, 16-byte loads).  The library
+// GEMV the host used for these ran at 280 us per call on [33 869 x 256] (rocprofv3, config 4: 4 calls per step, a fifth of the step).
+__global__ void __launch_bounds__(kT) gat_scores_fwd(const float* __restrict__ xl, int64_t N, int64_t D, const float* __restrict__ att_s,
+                                                    const float* __restrict__ att_d, float* __restrict__ a_s, float* __restrict__ a_d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
+    if (i >= N) return;
+    float s = 0.f, d = 0.f;
+    if ((D & 3) == 0) {
+        for (int64_t c = 4 * lane; c < D; c += 256) {
+            const float4 x = *reinterpret_cast<const float4*>(xl + i * D + c);
+            const float4 u = *reinterpret_cast<const float4*>(att_s + c);
+            const float4 v = *reinterpret_cast<const float4*>(att_d + c);
+            s = fmaf(x.x, u.x, fmaf(x.y, u.y, fmaf(x.z, u.z, fmaf(x.w, u.w, s))));
+            d = fmaf(x.x, v.x, fmaf(x.y, v.y, fmaf(x.z, v.z, fmaf(x.w, v.w, d))));
+        }
+    } else {
+        for (int64_t c = lane; c < D; c += 64) {
+            const float x = xl[i * D + c];
+            s = fmaf(x, att_s[c], s);
+            d = fmaf(x, att_d[c], d);
+        }
+    }
+    s = wave_sum_all(s);
+    d = wave_sum_all(d);
+    if (lane == 0) { a_s[i] = s; a_d[i] = d; }
+}
+
+// backward: dxl[i, :] (+)= g_s[i] att_s + g_d[i] att_d  (ACC: added to an existing gradient);  per-workgroup partial sums of
+// d att_s = sum_i g_s[i] x'[i, :], d att_d likewise (part [gridDim.x][2][D]; a second tiny launch adds them in order)
+template <bool ACC>
+__global__ void __launch_bounds__(kT) gat_scores_bwd(const float* __restrict__ xl, int64_t N, int64_t D, const float* __restrict__ att_s,
+                                                    const float* __restrict__ att_d, const float* __restrict__ g_s, const float* __restrict__ g_d,
+                                                    float* __restrict__ dxl, float* __restrict__ part, int rows_per_wg) {
+    // thread t owns column t (D <= 256 per pass); a workgroup walks rows_per_wg rows
+    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * rows_per_wg;
+    const int64_t r1 = r0 + rows_per_wg < N ? r0 + rows_per_wg : N;
+    for (int64_t cb = 0; cb < D; cb += kT) {
+        const int64_t c = cb + threadIdx.x;
+        const bool in = c < D;
+        const float us = in ? att_s[c] : 0.f, ud = in ? att_d[c] : 0.f;
+        float ps = 0.f, pd = 0.f;
+        for (int64_t i = r0; i < r1; ++i) {
+            const float gs = g_s[i], gd = g_d[i];
+            if (in) {
+                const float x = xl[i * D + c];
+                ps = fmaf(gs, x, ps);
+                pd = fmaf(gd, x, pd);
+                const float v = fmaf(gs, us, gd * ud);
+                dxl[i * D + c] = ACC ? dxl[i * D + c] + v : v;
+            }
+        }
+        if (in) {
+            part[(static_cast<int64_t>(blockIdx.x) * 2) * D + c] = ps;
+            part[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * D + c] = pd;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kT) gat_scores_bwd_finish(const float* __restrict__ part, int nwg, int64_t D, float* __restrict__ datt_s,
+                                                           float* __restrict__ datt_d) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
+    if (c >= 2 * D) return;
+    const int which = c >= D ? 1 : 0;
+    const int64_t cc = which ? c - D : c;
+    float acc = 0.f;
+    for (int w = 0; w < nwg; ++w) acc += part[(static_cast<int64_t>(w) * 2 + which) * D + cc];
+    (which ? datt_d : datt_s)[cc] = acc;
+}
+
 }  // namespace
 }  // namespace sgs
 
@@ -190,6 +260,44 @@ int sgs_scatter_by_eid(const float* in_order, const int32_t* eid, int64_t n, flo
     if (n == 0) return SGS_OK;
     SGS_REQUIRE(in_order && eid && by_eid, SGS_EINVAL, "sgs_scatter_by_eid: null pointer");
     hipLaunchKernelGGL(scatter_by_eid, dim3(cdiv(n, kT)), dim3(kT), 0, stream, in_order, eid, n, by_eid, dyn_edges_ptr());
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+int sgs_gat_scores_fwd(const float* xl, int64_t N, int64_t D, const float* att_src, const float* att_dst, float* a_src, float* a_dst,
+                       sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && D > 0, SGS_EINVAL, "sgs_gat_scores_fwd: bad sizes");
+    if (N == 0) return SGS_OK;
+    SGS_REQUIRE(xl && att_src && att_dst && a_src && a_dst, SGS_EINVAL, "sgs_gat_scores_fwd: null pointer");
+    hipLaunchKernelGGL(gat_scores_fwd, dim3(static_cast<unsigned>((N * 64 + kT - 1) / kT)), dim3(kT), 0, stream, xl, N, D, att_src, att_dst, a_src, a_dst);
+    SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+static inline int gat_scores_rows_per_wg(int64_t N) { return N >= 65536 ? 256 : (N >= 4096 ? 64 : 16); }
+size_t sgs_gat_scores_bwd_workspace_bytes(int64_t N, int64_t D) {
+    if (N < 0) N = 0;
+    if (D < 0) D = 0;
+    const int64_t rp = gat_scores_rows_per_wg(N);
+    return static_cast<size_t>((N + rp - 1) / rp) * 2 * D * 4 + 256;
+}
+
+int sgs_gat_scores_bwd(const float* xl, int64_t N, int64_t D, const float* att_src, const float* att_dst, const float* g_src, const float* g_dst,
+                       int accumulate, float* dxl, float* datt_src, float* datt_dst, void* ws, size_t ws_bytes, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(N >= 0 && D > 0, SGS_EINVAL, "sgs_gat_scores_bwd: bad sizes");
+    if (N == 0) return SGS_OK;
+    SGS_REQUIRE(xl && att_src && att_dst && g_src && g_dst && dxl && datt_src && datt_dst, SGS_EINVAL, "sgs_gat_scores_bwd: null pointer");
+    SGS_REQUIRE(ws && ws_bytes >= sgs_gat_scores_bwd_workspace_bytes(N, D), SGS_EWORKSPACE, "sgs_gat_scores_bwd: workspace too small");
+    const int rp = gat_scores_rows_per_wg(N);
+    const int nwg = static_cast<int>((N + rp - 1) / rp);
+    float* part = static_cast<float*>(ws);
+    if (accumulate)
+        hipLaunchKernelGGL((gat_scores_bwd<true>), dim3(nwg), dim3(kT), 0, stream, xl, N, D, att_src, att_dst, g_src, g_dst, dxl, part, rp);
+    else
+        hipLaunchKernelGGL((gat_scores_bwd<false>), dim3(nwg), dim3(kT), 0, stream, xl, N, D, att_src, att_dst, g_src, g_dst, dxl, part, rp);
+    hipLaunchKernelGGL(gat_scores_bwd_finish, dim3(static_cast<unsigned>((2 * D + kT - 1) / kT)), dim3(kT), 0, stream, part, nwg, D, datt_src, datt_dst);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }

@@ -130,8 +130,7 @@ class GATConv(nn.Module):
     def forward(self, x, edge_index, *, act=ops.ACT_NONE, p_act=0.0, seed=0, layer=0):
         graph = ops.get_graph(edge_index, x.shape[0])
         xl = self.lin_src(x)
-        a_s = xl @ self.att_src.reshape(-1)          # node-level dots (library GEMV)
-        a_d = xl @ self.att_dst.reshape(-1)
+        a_s, a_d = ops.gat_scores(xl, self.att_src, self.att_dst)      # node-level dots, one pass over x'
         p_att = self.dropout if self.training else 0.0
         return ops.gat_aggregate(xl, a_s, a_d, self.bias, graph, self.negative_slope, p_att, seed, SITE_GAT_ATT + 2 * layer, act,
                                  p_act, seed, SITE_GAT_ACT + layer)

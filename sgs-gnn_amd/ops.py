@@ -806,7 +806,7 @@ def _edge_score_backward_mask(ctx, L, codes, U, W1, b1, w2, b2, edge_index, eid,
     p = ctx.p
     bits = torch.empty(n, H // 32, dtype=torch.int32, device=dev)
     dz = torch.empty(n, **f32)
-    if kept and eid is not None and getattr(ctx, "src_sorted", False) and _fused_backward:
+    if kept and getattr(ctx, "src_sorted", False) and _fused_backward:      # (eid None: every edge active, in edge order -- sorted by source too)
         return _edge_score_backward_fused(ctx, L, codes, U, W1, b1, w2, edge_index, eid, graph, n, gp_act, kept, bits, dz)
     feat = torch.empty(n, H, **f32)
     hdz = Traw = craw = Rraw = None
@@ -1255,6 +1255,39 @@ class _GATAggregate(torch.autograd.Function):
         ones = torch.ones(N, 1, **f32)
         d_as = _spmm(ones, gr.out_ptr, gr.out_dst, g_out, g_self, None, ACT_NONE, 0.0, 0, 0, N, 1, n).reshape(N)
         return dxl, d_as, d_ad, dbias, None, None, None, None, None, None, None, None, None
+
+
+class _GATScores(torch.autograd.Function):
+    """a_s = x' att_src, a_d = x' att_dst (GATConv's node-level dots) in one pass over x' (sgs_gat_scores_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, xl, att_s, att_d):
+        L = _lib.lib()
+        N, D = xl.shape
+        a_s, a_d = torch.empty(N, dtype=torch.float32, device=xl.device), torch.empty(N, dtype=torch.float32, device=xl.device)
+        _lib.check(L.sgs_gat_scores_fwd(_ptr(xl, torch.float32), N, D, _ptr(att_s), _ptr(att_d), _ptr(a_s), _ptr(a_d), _stream()), "sgs_gat_scores_fwd")
+        ctx.save_for_backward(xl, att_s, att_d)
+        return a_s, a_d
+
+    @staticmethod
+    def backward(ctx, g_s, g_d):
+        L = _lib.lib()
+        xl, att_s, att_d = ctx.saved_tensors
+        N, D = xl.shape
+        dev = xl.device
+        g_s = torch.zeros(N, dtype=torch.float32, device=dev) if g_s is None else g_s.contiguous()
+        g_d = torch.zeros(N, dtype=torch.float32, device=dev) if g_d is None else g_d.contiguous()
+        dxl = torch.empty_like(xl)
+        das, dad = torch.empty(D, dtype=torch.float32, device=dev), torch.empty(D, dtype=torch.float32, device=dev)
+        ws = workspace(L.sgs_gat_scores_bwd_workspace_bytes(N, D), dev)
+        _lib.check(L.sgs_gat_scores_bwd(_ptr(xl), N, D, _ptr(att_s), _ptr(att_d), _ptr(g_s), _ptr(g_d), 0, _ptr(dxl), _ptr(das), _ptr(dad), ws.data_ptr(),
+                                        ws.numel(), _stream()), "sgs_gat_scores_bwd")
+        return dxl, das, dad
+
+
+def gat_scores(xl, att_src, att_dst):
+    _need_gpu(xl, att_src, att_dst)
+    return _GATScores.apply(xl.contiguous(), att_src.reshape(-1).contiguous(), att_dst.reshape(-1).contiguous())
 
 
 def gat_aggregate(xl, a_s, a_d, bias, graph: Graph, negative_slope=0.2, p_att=0.0, seed_att=0, site_att=0, act=ACT_NONE,
