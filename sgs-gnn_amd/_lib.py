@@ -7,7 +7,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "sgs_hip.h")
-LIB_PATH = os.path.join(_HERE, "libsgs_hip.so")
+LIB_PATH = os.environ.get("SGS_LIB_PATH") or os.path.join(_HERE, "libsgs_hip.so")
 
 _SCALARS = {
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "uint32_t": ctypes.c_uint32,

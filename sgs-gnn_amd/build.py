@@ -16,8 +16,13 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libsgs_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
-         "-fgpu-rdc" if False else "-fno-gpu-rdc"]
+# -fno-slp-vectorize: under plain -O3 hipcc packs adjacent scalar fp32 adds / multiplies of the kernels' epilogues into v_pk_add_f32 /
+# v_pk_mul_f32.  Beside MFMAs those are slower than the scalar forms (MI355X_MICROARCH.md, "packed f32 VALU ... an anti-lever"), and a
+# round-3 build of the paired scorer forward that contained them was NOT run-to-run deterministic at N = 33 869 (a few lanes of a wave
+# off by one hidden unit's bias term in ~half of the launches; tools/dbg_det2.py: 27-60 of 60 runs with, 0 of 60 without the packing;
+# tests/test_gpu_edge_score.py::test_paired_forward_is_run_to_run_deterministic_at_arxiv_size).
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
+         "-fno-gpu-rdc"]
 
 
 def _stale(target, deps):

@@ -1005,7 +1005,17 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
     // Counters showed the waves of this kernel waiting on memory for 60 % of their life, and most of that here: with one step
     // of look-ahead each of the 32 steps exposed a gather latency.  The main loop's operand registers are dead now, so the
     // endpoint rows of U are gathered kPF steps ahead, and b1 / w2 (the same for every edge) come from LDS.
+#ifdef SGS_DBG_KPF
+    constexpr int kPF = SGS_DBG_KPF;
+#else
     constexpr int kPF = 8;
+#endif
+    // Every memory operation of the main loop is retired before the epilogue begins.  The last phase issues loads whose results nothing
+    // reads (it "reloads its own chunks" to stay branch-free); their destination registers are dead after the loop and get new tenants
+    // here, and a build of round 3 produced scores that differed from run to run in a few lanes of a wave by one hidden unit's bias term
+    // (N = 33 869: the codes table is not L2-resident, so those loads return late).  Draining costs a fraction of a microsecond per wave.
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_sched_barrier(0);
     const int Hrt = a.H;
     const uint32_t rkey = dropout_row_key(fold_epoch(a.seed, a.epoch), a.site, static_cast<uint64_t>(a.row_offset + eg_id));
     int64_t mate_id = -1;                                         // MODE 3: the reverse edge, finished from the same accumulators
@@ -1037,8 +1047,13 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
         if (8 * i < Hrt) {                           // always true: one basic block per step keeps the look-ahead at kPF steps
             const int t = i >> 2, g4 = i & 3;
             const int hb = 8 * i + 4 * kh;
+#ifdef SGS_DBG_BW_GLOBAL
+            const float4 bb = *reinterpret_cast<const float4*>(a.b1 + hb);
+            const float4 ww = *reinterpret_cast<const float4*>(a.w2 + hb);
+#else
             const float4 bb = *reinterpret_cast<const float4*>(&bw[0][hb]);
             const float4 ww = *reinterpret_cast<const float4*>(&bw[1][hb]);
+#endif
             const float4 su = us[i % kPF], du = ud[i % kPF];
             const float u4[4] = {su.x - du.x, su.y - du.y, su.z - du.z, su.w - du.w};
             const float b4[4] = {bb.x, bb.y, bb.z, bb.w};

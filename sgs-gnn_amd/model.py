@@ -95,6 +95,7 @@ class GNNModel(nn.Module):
     def forward(self, data, edge_index, edge_weight=None):
         from .utils import segment
         x = data.x
+        ops.feature_csr(x, build=True)                            # bag-of-words features: the first layer runs over their non-zeros (once per graph)
         with segment(self, "gnn_forward"):                        # model.py:156-163
             norm = ops.gcn_norm(ops.get_graph(edge_index, x.shape[0]), edge_weight)   # once for both layers
             p = self.dropout.p if self.training else 0.0

@@ -1397,9 +1397,10 @@ _FEAT_SPARSE_MAX_DENSITY = 0.05        # above this the library GEMM wins
 _FEAT_SPARSE_MIN_ELEMS = 1 << 22       # small matrices: not worth a second code path
 
 
-def feature_csr(x: torch.Tensor, build: bool = True):
+def feature_csr(x: torch.Tensor, build: bool = False):
     """FeatCSR of `x` if it is sparse enough (cached on the tensor, keyed by its version), else None.  Building reads the non-zero count
-    back (set-up work, once per graph); inside a stream capture only an existing cache entry is used."""
+    back (set-up work, once per graph): only the models' FIRST layers ask for it (`build=True`, on the batch's resident x); the products
+    themselves just look the cache up.  Inside a stream capture only an existing cache entry is used."""
     c = getattr(x, "_sgs_fcsr", None)
     if c is not None and c[1] == x._version:
         return c[0]

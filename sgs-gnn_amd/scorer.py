@@ -30,6 +30,7 @@ class EdgeProbGCN(nn.Module):
         N = node_features.shape[0]
         p = self.dropout.p if self.training else 0.0
         act = ops.ACT_RELU_DROPOUT if p > 0 else ops.ACT_RELU
+        ops.feature_csr(node_features, build=True)                # sparse bag-of-words features: x W^T over their non-zeros (cached per graph)
         with segment(self, "edge_mlp_pre"):                       # model.py:103-112
             norm = ops.gcn_norm(ops.get_graph(g, N), None)
             out = self.gcn1(node_features, g, norm=norm, act=act, p=p, seed=_DropoutClock.next_seed(), site=SITE_ENC)

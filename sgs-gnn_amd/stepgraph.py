@@ -288,7 +288,7 @@ class StepGraphs:
         """Does the partition fit the slots' static feature-CSR buffers (trivially true when the slots carry none)?"""
         if not self.fcsr_cap:
             return True
-        fc = ops.feature_csr(batch.x)
+        fc = ops.feature_csr(batch.x, build=True)
         return fc is not None and fc.nnz <= self.fcsr_cap
 
     # ------------------------------------------------------------------ slots and staging
@@ -361,7 +361,7 @@ class StepGraphs:
             m4 = torch.zeros(_round_up(N, 4), dtype=torch.uint8, device=batch.x.device)
             m4[:N] = ops._u8(batch.train_mask)
             src = dict(graph=g, mask4=m4, x=batch.x.contiguous(), y=batch.y.contiguous(), norm=ops.gcn_norm(g, None) if want_norm else None,
-                       pairs=ops.get_pairs(batch.edge_index, N, build=True) if want_pairs else None, fcsr=ops.feature_csr(batch.x))
+                       pairs=ops.get_pairs(batch.edge_index, N, build=True) if want_pairs else None, fcsr=ops.feature_csr(batch.x, build=True))
             try:
                 batch._sgs_stage_src = src
             except Exception:

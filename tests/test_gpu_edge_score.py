@@ -523,3 +523,26 @@ def test_endpoint_dropout_scorer_vs_fp64_oracle(ops, N, H, E, q, p):
     for name, a, b in zip(["dA", "dW1", "db1", "dW2", "db2"], [t.grad for t in dl], [Ao.grad, Po[0].grad, Po[1].grad, Po[2].grad, Po[3].grad]):
         assert bool(torch.isfinite(a).all()), name
         assert _rel(a, b.reshape(a.shape)) < 2e-5, (name, _rel(a, b.reshape(a.shape)))
+
+
+def test_paired_forward_is_run_to_run_deterministic_at_arxiv_size(ops):
+    """Config 4's partition size (n = 33 869: the codes table is 34 MB, not L2-resident; E = 463 k): the paired forward -- plain and
+    mask-keeping -- must give the same bits on every launch.  A round-3 build with SLP-packed fp32 epilogue arithmetic (v_pk_add_f32 /
+    v_pk_mul_f32) did not (sgs-gnn_amd/build.py: -fno-slp-vectorize); this is the regression test for that."""
+    import sgs_gnn_amd as S
+    n, H = 33_869, 256
+    b = S.synthetic_graph(n, 463_000, 8, 5, seed=300, train_frac=0.2, power=0.6, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    codes = torch.relu(torch.randn(n, H, device=DEV, generator=g))
+    W1 = torch.randn(H, 2 * H, device=DEV, generator=g) / (2 * H) ** 0.5
+    b1 = torch.randn(H, device=DEV, generator=g) * 0.05
+    W2 = torch.randn(1, H, device=DEV, generator=g) / H ** 0.5
+    b2 = torch.zeros(1, device=DEV)
+    pairs = ops.get_pairs(b.edge_index, n, build=True)
+    for grad in (False, True):
+        cd = codes.clone().requires_grad_(grad)                      # grad: the mask-keeping forward of a training step
+        with torch.set_grad_enabled(grad):
+            p0 = ops.edge_score(cd, W1, b1, W2, b2, b.edge_index, pairs=pairs, p=0.3, seed=3, site=2).detach().clone()
+            for it in range(25):
+                p1 = ops.edge_score(cd, W1, b1, W2, b2, b.edge_index, pairs=pairs, p=0.3, seed=3, site=2).detach()
+                assert torch.equal(p1, p0), (grad, it, int((p1 != p0).sum()))

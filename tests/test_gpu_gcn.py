@@ -257,14 +257,14 @@ def test_sparse_feature_products_match_dense_and_replay_through_the_slots():
         x = (torch.rand(n, F_, device=DEV, generator=gg) < 0.01).float() * torch.rand(n, F_, device=DEV, generator=gg)
         return x / x.sum(1, keepdim=True).clamp_min(1e-12)
     x = feats(N, 1)
-    fc = ops.feature_csr(x)
+    fc = ops.feature_csr(x, build=True)
     assert fc is not None and fc.nnz == int((x != 0).sum()) and fc.N == N and fc.F == F_
     W = torch.randn(H, F_, device=DEV, generator=g) * 0.05
     dY = torch.randn(N, H, device=DEV, generator=g)
     torch.testing.assert_close(ops._x_wt(x, W), x @ W.t(), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(ops._dyt_x(dY, x, W.shape), dY.t() @ x, rtol=1e-4, atol=1e-6)
     dense = torch.randn(N, F_, device=DEV, generator=g)
-    assert ops.feature_csr(dense) is None                               # N(0,1) features (Reddit): the library GEMM
+    assert ops.feature_csr(dense, build=True) is None                               # N(0,1) features (Reddit): the library GEMM
     # (3) graph mode against eager on two partitions of different sizes / nnz
     crit = torch.nn.CrossEntropyLoss()
     bs = []
@@ -286,7 +286,7 @@ def test_sparse_feature_products_match_dense_and_replay_through_the_slots():
         return rets, m
     r_e, m_e = run(False)
     r_g, m_g = run(True)
-    assert m_g._sgs_stepgraphs.fcsr_cap >= max(ops.feature_csr(b.x).nnz for b in bs)
+    assert m_g._sgs_stepgraphs.fcsr_cap >= max(ops.feature_csr(b.x, build=True).nnz for b in bs)
     assert r_e == r_g
     for (k, a_), (_, b_) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
         assert torch.equal(a_, b_), k
