@@ -789,6 +789,19 @@ __global__ void __launch_bounds__(kT) pack_w1a_bf16x3(const float* __restrict__ 
 // sign of the node-level term U[s] - U[d] and in their dropout rows.  So only the canonical edge of every mated pair (and every
 // unmated edge) runs the main loop -- about half of the candidate edges -- and the epilogue finishes BOTH scores from the one
 // set of accumulators: the same p as MODE 0, bit for bit, at ~0.6 x the time.
+// acc <- (acc << 1) | [this lane's bit of `mask`] as ONE vector instruction: v_addc_co_u32 acc, acc + acc + carry-in, the carry-in taken
+// per lane from a 64-bit lane mask (the result of a vector compare).  The scorer's forward epilogue builds its ReLU x dropout mask words
+// with it: one instruction per hidden unit instead of min / shift / or.
+__device__ __forceinline__ uint32_t shift_in_bit(uint32_t acc, uint64_t mask) {
+    uint32_t out;
+    uint64_t carry_out;
+    // (s_nop 1: gfx950 wants two wait states between a vector compare's SGPR result and a vector instruction that reads it as a mask; the
+    //  compiler pads its own instructions but does not look inside inline assembly -- without the pad the mask words of a no-dropout
+    //  forward came out wrong in a few lanes)
+    asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(out), "=s"(carry_out) : "v"(acc), "s"(mask));
+    return out;
+}
+
 template <int NT, int NW, int MODE = 0>
 __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(ScoreArgs a, const uint4* __restrict__ Wp16) {
     constexpr bool BWD = MODE == 1, FUSED = MODE == 5, GEMMB = MODE == 4 || MODE == 5, GEMM = MODE == 2 || GEMMB, PAIR = MODE == 3;
@@ -809,7 +822,11 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
         if (row0 >= a.n) return;                                  // (uniform per workgroup, before any barrier)
     }
     if (!GEMM)
-        for (int i = tid; i < H; i += TH) { bw[0][i] = a.b1[i]; bw[1][i] = a.w2[i]; }    // (visible after the first barrier below)
+        for (int i = tid; i < H; i += TH) {                                               // (visible after the first barrier below)
+            bw[0][i] = a.b1[i];
+            // forward modes: fc2's weight with the dropout scale folded in (z += (w2 / (1 - p)) * relu(v) on the kept units)
+            bw[1][i] = (!BWD && a.use_drop) ? a.w2[i] * a.drop_scale : a.w2[i];
+        }
     const int64_t r = row0 + 32 * wave + l31;
     const bool live = r < a.n;
     int s = 0, d = 0;
@@ -1005,11 +1022,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
     // Counters showed the waves of this kernel waiting on memory for 60 % of their life, and most of that here: with one step
     // of look-ahead each of the 32 steps exposed a gather latency.  The main loop's operand registers are dead now, so the
     // endpoint rows of U are gathered kPF steps ahead, and b1 / w2 (the same for every edge) come from LDS.
-#ifdef SGS_DBG_KPF
-    constexpr int kPF = SGS_DBG_KPF;
-#else
-    constexpr int kPF = 8;
-#endif
+    constexpr int kPF = BWD ? 8 : (PAIR ? 5 : 6);          // (forward: four straight-line copies of the step loop share the register file)
     // Every memory operation of the main loop is retired before the epilogue begins.  The last phase issues loads whose results nothing
     // reads (it "reloads its own chunks" to stay branch-free); their destination registers are dead after the loop and get new tenants
     // here, and a build of round 3 produced scores that differed from run to run in a few lanes of a wave by one hidden unit's bias term
@@ -1028,10 +1041,120 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
     const float* Us = a.U + static_cast<int64_t>(s) * H + 4 * kh;
     const float* Ud = a.U + static_cast<int64_t>(d) * H + 4 * kh;
     float4 us[kPF], ud[kPF];
+    if constexpr (BWD) {
 #pragma unroll
-    for (int i = 0; i < kPF; ++i) {
-        us[i] = *reinterpret_cast<const float4*>(Us + 8 * i);
-        ud[i] = *reinterpret_cast<const float4*>(Ud + 8 * i);
+        for (int i = 0; i < kPF; ++i) {
+            us[i] = *reinterpret_cast<const float4*>(Us + 8 * i);
+            ud[i] = *reinterpret_cast<const float4*>(Ud + 8 * i);
+        }
+    }
+    if constexpr (!BWD) {
+        // ---- forward epilogue (MODE 0 and the paired MODE 3), written for the vector-instruction count: the two waves of a SIMD run it at
+        // the same time, so its instructions are not hidden behind anyone's MFMAs.  Per hidden unit and edge: v = (acc + b1) +/- (U[s] - U[d])
+        // (acc + b1 shared by the pair), two compares (v > 0; draw >= threshold, the 16-bit draw selected by the compare itself), their AND on
+        // the scalar unit, one select, one FMA into one of four partial sums (w2 / (1 - p) comes pre-scaled from LDS), one carry-in add for the
+        // mask bit.  Steps run from the last hidden unit down: the mask words fill from the top, so bit 8 g4 + j lands in place.
+        const bool want_bits = a.dvbits != nullptr;
+        const bool use_drop = a.use_drop != 0;
+        const uint32_t thr = a.drop_thresh;
+        float zA[2] = {0.f, 0.f}, zB[2] = {0.f, 0.f};      // two partial sums per edge (even / odd hidden units)
+        uint32_t fb[NT], fb2[PAIR ? NT : 1];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fb[t] = 0u;
+#pragma unroll
+        for (int t = 0; t < (PAIR ? NT : 1); ++t) fb2[t] = 0u;
+#pragma unroll
+        for (int k = 0; k < kPF; ++k) {                 // the ring starts with the LAST kPF steps
+            us[k] = *reinterpret_cast<const float4*>(Us + 8 * (4 * NT - 1 - k));
+            ud[k] = *reinterpret_cast<const float4*>(Ud + 8 * (4 * NT - 1 - k));
+        }
+        // four straight-line copies of the loop (dropout on / off x mask kept / not), chosen once per wave: the two questions cost a
+        // compare and a branch per hidden unit when asked inside
+        auto steps = [&](auto DROP_, auto BITS_) {
+            constexpr bool DROP = decltype(DROP_)::value, BITS = decltype(BITS_)::value;
+#pragma unroll
+            for (int ii = 0; ii < 4 * NT; ++ii) {
+                if (8 * ii < Hrt) {                      // always true: one basic block per step keeps the look-ahead at kPF steps
+                    const int i = 4 * NT - 1 - ii, t = i >> 2, g4 = i & 3;
+                    const int hb = 8 * i + 4 * kh;
+                    const float4 bb = *reinterpret_cast<const float4*>(&bw[0][hb]);
+                    const float4 ww = *reinterpret_cast<const float4*>(&bw[1][hb]);
+                    const float4 su = us[ii % kPF], du = ud[ii % kPF];
+                    const float d4[4] = {su.x - du.x, su.y - du.y, su.z - du.z, su.w - du.w};
+                    const float b4[4] = {bb.x, bb.y, bb.z, bb.w};
+                    const float w4[4] = {ww.x, ww.y, ww.z, ww.w};
+                    if (ii + kPF < 4 * NT) {
+                        us[ii % kPF] = *reinterpret_cast<const float4*>(Us + 8 * (i - kPF));
+                        ud[ii % kPF] = *reinterpret_cast<const float4*>(Ud + 8 * (i - kPF));
+                    }
+                    uint32_t bits[2] = {0u, 0u}, bits2[2] = {0u, 0u};
+                    if constexpr (DROP) {
+                        bits[0] = dropout_pair_bits(rkey, static_cast<uint32_t>(hb >> 1));
+                        bits[1] = dropout_pair_bits(rkey, static_cast<uint32_t>((hb >> 1) + 1));
+                        if constexpr (PAIR) {
+                            bits2[0] = dropout_pair_bits(rkey2, static_cast<uint32_t>(hb >> 1));
+                            bits2[1] = dropout_pair_bits(rkey2, static_cast<uint32_t>((hb >> 1) + 1));
+                        }
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int j = 3 - jj;
+                        const float tb = acc[t][4 * g4 + j] + b4[j];
+                        const float v = tb + d4[j];
+                        bool on = v > 0.f;
+                        if constexpr (DROP) on = on & (((j & 1) ? (bits[j >> 1] >> 16) : (bits[j >> 1] & 0xFFFFu)) >= thr);
+                        zA[j & 1] = fmaf(w4[j], on ? v : 0.f, zA[j & 1]);
+                        if constexpr (BITS) fb[t] = shift_in_bit(fb[t], __builtin_amdgcn_ballot_w64(on));
+                        if constexpr (PAIR) {
+                            const float v2 = tb - d4[j];                     // the mate: the node-level term with the opposite sign
+                            bool on2 = v2 > 0.f;
+                            if constexpr (DROP) on2 = on2 & (((j & 1) ? (bits2[j >> 1] >> 16) : (bits2[j >> 1] & 0xFFFFu)) >= thr);
+                            zB[j & 1] = fmaf(w4[j], on2 ? v2 : 0.f, zB[j & 1]);
+                            if constexpr (BITS) fb2[PAIR ? t : 0] = shift_in_bit(fb2[PAIR ? t : 0], __builtin_amdgcn_ballot_w64(on2));
+                        }
+                    }
+                    if constexpr (BITS) {
+                        if (g4 != 0) {                                       // the other half-wave's nibble goes between two groups
+                            fb[t] <<= 4;
+                            if constexpr (PAIR) fb2[PAIR ? t : 0] <<= 4;
+                        }
+                    }
+                }
+            }
+        };
+        if (use_drop) { if (want_bits) steps(std::true_type{}, std::true_type{}); else steps(std::true_type{}, std::false_type{}); }
+        else          { if (want_bits) steps(std::false_type{}, std::true_type{}); else steps(std::false_type{}, std::false_type{}); }
+        float z = zA[0] + zA[1];
+        float zm = zB[0] + zB[1];
+        if (want_bits) {                                                 // join the two kh halves of every word, one lane stores the row
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { fb[t] <<= 4 * kh; fb[t] |= __shfl_xor(fb[t], 32, 64); }
+            if (live && kh == 0) {
+                uint4* bo = reinterpret_cast<uint4*>(a.dvbits + eg_id * NT);
+#pragma unroll
+                for (int t = 0; t < NT; t += 4) bo[t >> 2] = make_uint4(fb[t], fb[t + 1], fb[t + 2], fb[t + 3]);
+            }
+            if constexpr (PAIR) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { fb2[t] <<= 4 * kh; fb2[t] |= __shfl_xor(fb2[t], 32, 64); }
+                if (live && kh == 0 && mate_id >= 0) {
+                    uint4* bo = reinterpret_cast<uint4*>(a.dvbits + mate_id * NT);
+#pragma unroll
+                    for (int t = 0; t < NT; t += 4) bo[t >> 2] = make_uint4(fb2[t], fb2[t + 1], fb2[t + 2], fb2[t + 3]);
+                }
+            }
+        }
+        z += __shfl_xor(z, 32, 64);
+        if constexpr (PAIR) {
+            zm += __shfl_xor(zm, 32, 64);
+            if (live && kh == 0) {
+                a.p_out[eg_id] = 1.0f / (1.0f + expf(-(z + a.b2[0])));
+                if (mate_id >= 0) a.p_out[mate_id] = 1.0f / (1.0f + expf(-(zm + a.b2[0])));
+            }
+        } else {
+            if (live && kh == 0) a.p_out[r] = 1.0f / (1.0f + expf(-(z + a.b2[0])));
+        }
+        return;
     }
     float z = 0.f;
     // forward with `dvbits`: the ReLU x dropout mask of every scored edge, one bit per hidden unit (bit h of edge e in word h / 32 of row e)
@@ -1047,13 +1170,8 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
         if (8 * i < Hrt) {                           // always true: one basic block per step keeps the look-ahead at kPF steps
             const int t = i >> 2, g4 = i & 3;
             const int hb = 8 * i + 4 * kh;
-#ifdef SGS_DBG_BW_GLOBAL
-            const float4 bb = *reinterpret_cast<const float4*>(a.b1 + hb);
-            const float4 ww = *reinterpret_cast<const float4*>(a.w2 + hb);
-#else
             const float4 bb = *reinterpret_cast<const float4*>(&bw[0][hb]);
             const float4 ww = *reinterpret_cast<const float4*>(&bw[1][hb]);
-#endif
             const float4 su = us[i % kPF], du = ud[i % kPF];
             const float u4[4] = {su.x - du.x, su.y - du.y, su.z - du.z, su.w - du.w};
             const float b4[4] = {bb.x, bb.y, bb.z, bb.w};
@@ -1089,7 +1207,9 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float v = (acc[t][4 * g4 + j] + u4[j]) + b4[j];
+                // (same order of additions as the forward epilogue above: the recomputed ReLU mask must equal the kept one bit for bit,
+                //  and a unit with |v| ~ 1e-8 flips with the order)
+                const float v = (acc[t][4 * g4 + j] + b4[j]) + u4[j];
                 float m = v > 0.f ? 1.f : 0.f;
                 if (a.use_drop) {
                     const uint32_t draw = (j & 1) ? (bits[j >> 1] >> 16) : (bits[j >> 1] & 0xFFFFu);
