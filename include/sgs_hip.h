@@ -404,6 +404,13 @@ int sgs_edge_score_dw2_from_parts(const float* W1, const float* T_raw, const flo
  *                                (then d W1 = dv^T feat2 by sgs_gemm_tn, dfeat2 = dv W1 by a library GEMM)
  *   sgs_edge_score_epd_reduce    d A [N, H] from dfeat2 [n, 2H] over both CSR orientations of the active edge list (masks recomputed)
  * ws: sgs_edge_score_epd_workspace_bytes(H). */
+/* Probe knobs of the bf16x6 scorer kernels (tools/stagger_probe.py, tools/stagger_trace.py; the product path never calls them).
+ * `stagger` >= 0 forces the start-up sleep of every CU's second resident workgroup (in 64-cycle quanta; -1 = the built-in policy),
+ * `prio` = 1 runs the main loop at raised wave priority, 2 the epilogue; `mode_mask` = bit m set: kernel MODE m staggers. */
+int sgs_edge_score_probe_set(int stagger, int prio, uint32_t mode_mask);
+/* `buf` (device, 8 words per workgroup of the next launches, or NULL = off): shader-clock stamps at kernel start, main loop,
+ * epilogue and end, and the hardware id of the CU the workgroup ran on. */
+int sgs_edge_score_probe_trace(unsigned long long* buf);
 size_t sgs_edge_score_epd_workspace_bytes(int64_t H);
 int sgs_edge_score_epd_fwd(const float* A, int64_t N, int64_t H, const int64_t* edge_index, int64_t E, int64_t edge_id_offset, const float* W1,
                            const float* b1, const float* w2, const float* b2, float p_hidden, uint64_t seed, uint32_t site, float p_ep,

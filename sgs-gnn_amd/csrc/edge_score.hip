@@ -97,6 +97,10 @@ struct ScoreArgs {
     uint32_t ep_thresh;
     const int32_t* sd;       // MODE 5: [n, 2] (src, dst) of every active row
     float* opart;            // MODE 5: [cdiv(n, 32) + N, H] run-end partial sums of dfeat * codes[dst] (see the kernel)
+    // bf16x6 kernels: start-up stagger of every CU's second resident workgroup, in 64-cycle sleeps (0 = none; see the kernel), and the probe
+    // knobs of tools/stagger_probe.py / stagger_trace.py (0 / NULL in the product path)
+    int stagger, prio;
+    unsigned long long* trace;
 };
 
 // Workgroup = 64 edges x all HP = 32*NT hidden units; wave (eg, hh) owns edges 32eg..32eg+31 and
@@ -802,6 +806,8 @@ __device__ __forceinline__ uint32_t shift_in_bit(uint32_t acc, uint64_t mask) {
     return out;
 }
 
+#define SGS_STAMP(k) do { if (a.trace && tid == 0) a.trace[8 * blockIdx.x + (k)] = __builtin_readcyclecounter(); } while (0)
+
 template <int NT, int NW, int MODE = 0>
 __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(ScoreArgs a, const uint4* __restrict__ Wp16) {
     constexpr bool BWD = MODE == 1, FUSED = MODE == 5, GEMMB = MODE == 4 || MODE == 5, GEMM = MODE == 2 || GEMMB, PAIR = MODE == 3;
@@ -820,6 +826,22 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
         const int64_t live_n = *a.dyn_n;
         if (live_n < a.n) a.n = live_n;
         if (row0 >= a.n) return;                                  // (uniform per workgroup, before any barrier)
+    }
+    // Two workgroups share a CU, one wave of each per SIMD.  Started together they stay in step: both in the MFMA loop (sharing the matrix
+    // pipe), then both in the epilogue (the pipe idle; counters, round 3: busy 42 % of the cycles).  The workgroups that take the SECOND
+    // slot of every CU at kernel start (256 .. 511 in dispatch order) therefore sleep for about half a main loop first; every later
+    // workgroup starts when a slot frees and inherits the offset.  Shader-clock stamps (tools/stagger_trace.py, E = 351 194): main loop
+    // 60.6k -> 46.2k cycles per workgroup, kernel 234 -> 199 us.  Only for launches of >= 1 024 live workgroups (two per slot): the sleep
+    // idles half the chip for ~20 us once.
+    if (a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512 && a.n >= static_cast<int64_t>(1024) * 32 * NW)
+        for (int w = 0; w < a.stagger; ++w) __builtin_amdgcn_s_sleep(1);
+    if ((a.prio & 3) == 1) __builtin_amdgcn_s_setprio(1);
+    SGS_STAMP(0);
+    if (a.trace && tid == 0) {
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.trace[8 * blockIdx.x + 4] = (static_cast<unsigned long long>(xcc) << 32) | hw;
     }
     if (!GEMM)
         for (int i = tid; i < H; i += TH) {                                               // (visible after the first barrier below)
@@ -874,78 +896,117 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
     fload(0, fa);
     lstore(wl[0]);
     __syncthreads();
-    // one k-chunk: split the (dead afterwards) fp32 features, refill them with chunk `kn_` of the next phase, 6 NT MFMAs
-    auto chunk = [&](const uint4* wcur, Feat& f, int kc_, int kn_) {
-        u32x4 F1, F2, F3;
+    SGS_STAMP(1);
+    // Software pipeline over the k-chunks.  Phase ph runs the 6 NT MFMAs of chunk ph on operand pieces that the PREVIOUS phase split, and in
+    // the gaps behind its first MFMAs (an MFMA holds the SIMD's vector issue for 8 of its 32 cycles: six or seven vector instructions fit)
+    // splits the fp32 features of chunk ph + 1, then refills their registers with chunk ph + 2.  (Round 3, shader-clock stamps: with the
+    // whole split ahead of the MFMAs and the first W fragments read just before them, a phase took ~2 800 cycles for 1 536 cycles of MFMAs.)
+    struct Pieces { u32x4 F1, F2, F3; };
+    struct SplitState { float a, b; uint32_t p1; float4 pa, pb; };
+    // slot 2 j: products of pair j, its first piece and the remainders; slot 2 j + 1: second and third piece.  (split3(), in two halves.)
+    auto split_slot = [&](int slot, Feat& f, int kc_, bool wr, Pieces& P, SplitState& st) {
+        const int j = slot >> 1;
         if constexpr (GEMMB) {
-            // eight mask bits -> eight bf16 ones / zeros: ONE exact piece, so a chunk is 3 MFMAs per tile (the pieces of the matrix)
-            const uint32_t b = f.mb;
+            if (slot != 0) return;
+            const uint32_t b = f.mb;                 // eight mask bits -> eight bf16 ones / zeros: ONE exact piece (3 MFMAs per tile)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) F1[m] = ((b >> (2 * m)) & 1u ? 0x3F80u : 0u) | ((b >> (2 * m + 1)) & 1u ? 0x3F800000u : 0u);
-            F2 = F1; F3 = F1;
+            for (int m = 0; m < 4; ++m) P.F1[m] = ((b >> (2 * m)) & 1u ? 0x3F80u : 0u) | ((b >> (2 * m + 1)) & 1u ? 0x3F800000u : 0u);
+            P.F2 = P.F1; P.F3 = P.F1;
         } else {
-            const float4 pa = GEMM ? f.xa : make_float4(f.xa.x * f.ya.x, f.xa.y * f.ya.y, f.xa.z * f.ya.z, f.xa.w * f.ya.w);
-            const float4 pb = GEMM ? f.xb : make_float4(f.xb.x * f.yb.x, f.xb.y * f.yb.y, f.xb.z * f.yb.z, f.xb.w * f.yb.w);
-            if (BWD && live) {                       // feat[e, k] = x_s[k] x_d[k], k = 16 kc + 8 kh .. + 7, for the weight gradient
-                float4* fo = reinterpret_cast<float4*>(a.feat + r * H + 16 * kc_ + 8 * kh);
-                fo[0] = pa;
-                fo[1] = pb;
+            if ((slot & 1) == 0) {
+                const float4 x = j < 2 ? f.xa : f.xb, y = j < 2 ? f.ya : f.yb;
+                const float x0 = (j & 1) ? x.z : x.x, x1 = (j & 1) ? x.w : x.y, y0 = (j & 1) ? y.z : y.x, y1 = (j & 1) ? y.w : y.y;
+                st.a = GEMM ? x0 : x0 * y0;
+                st.b = GEMM ? x1 : x1 * y1;
+                if constexpr (BWD) {                 // feat[e, k] = x_s[k] x_d[k], k = 16 kc + 8 kh .. + 7, for the weight gradient
+                    float4& pp = j < 2 ? st.pa : st.pb;
+                    if (j & 1) { pp.z = st.a; pp.w = st.b; } else { pp.x = st.a; pp.y = st.b; }
+                    if ((j & 1) && live && wr) reinterpret_cast<float4*>(a.feat + r * H + 16 * kc_ + 8 * kh)[j >> 1] = pp;
+                }
+                const uint32_t p1 = pk_bf16(st.a, st.b);
+                st.a -= __uint_as_float(p1 << 16);
+                st.b -= __uint_as_float(p1 & 0xFFFF0000u);
+                P.F1[j] = p1;
+            } else {
+                const uint32_t p2 = pk_bf16(st.a, st.b);
+                st.a -= __uint_as_float(p2 << 16);
+                st.b -= __uint_as_float(p2 & 0xFFFF0000u);
+                P.F2[j] = p2;
+                P.F3[j] = pk_bf16(st.a, st.b);
             }
-            uint32_t p1, p2, p3;
-            split3(pa.x, pa.y, p1, p2, p3); F1[0] = p1; F2[0] = p2; F3[0] = p3;
-            split3(pa.z, pa.w, p1, p2, p3); F1[1] = p1; F2[1] = p2; F3[1] = p3;
-            split3(pb.x, pb.y, p1, p2, p3); F1[2] = p1; F2[2] = p2; F3[2] = p3;
-            split3(pb.z, pb.w, p1, p2, p3); F1[3] = p1; F2[3] = p2; F3[3] = p3;
         }
-        const bf16x8 f1 = __builtin_bit_cast(bf16x8, F1), f2 = __builtin_bit_cast(bf16x8, F2), f3 = __builtin_bit_cast(bf16x8, F3);
-        __builtin_amdgcn_sched_barrier(0);
-        fload(kn_, f);
-        // W fragments one tile ahead of the MFMAs that use them (the compiler, left alone, reads each just in time and
-        // exposes the LDS latency eight times per chunk)
+    };
+    constexpr int kSlots = GEMMB ? 1 : 8;
+    auto split_feat = [&](Feat& f, int kc_, bool wr, Pieces& P) {
+        SplitState st;
+#pragma unroll
+        for (int q = 0; q < kSlots; ++q) split_slot(q, f, kc_, wr, P, st);
+    };
+    unsigned long long pst[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // probe: stamps inside phase 8 (a.trace only)
+    auto chunk = [&](const uint4* wcur, const Pieces& C, Pieces& Nx, Feat& f, int kc1, int kn_, bool wr, bool tr) {
+        const bf16x8 f1 = __builtin_bit_cast(bf16x8, C.F1), f2 = __builtin_bit_cast(bf16x8, C.F2), f3 = __builtin_bit_cast(bf16x8, C.F3);
         auto wload = [&](int t, WF& w) {
             w.q1 = wcur[(t * 3 + 0) * 64 + lane];
             w.q2 = wcur[(t * 3 + 1) * 64 + lane];
             w.q3 = wcur[(t * 3 + 2) * 64 + lane];
         };
-        auto six = [&](int t, const WF& w) {
+        constexpr int kPerTile = GEMMB ? 3 : 6;
+        auto one = [&](int t, const WF& w, int m) {          // smallest terms first
             const bf16x8 w1 = __builtin_bit_cast(bf16x8, w.q1), w2 = __builtin_bit_cast(bf16x8, w.q2), w3 = __builtin_bit_cast(bf16x8, w.q3);
-            // smallest terms first
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, f1, acc[t], 0, 0, 0);
             if constexpr (GEMMB) {
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, f1, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, f1, acc[t], 0, 0, 0);
-                return;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m == 0 ? w3 : m == 1 ? w2 : w1, f1, acc[t], 0, 0, 0);
+            } else {
+                const bf16x8 wm = m == 0 ? w3 : (m == 1 || m == 3) ? w2 : w1;
+                const bf16x8 fm = (m == 0 || m == 3 || m == 5) ? f1 : (m == 1 || m == 4) ? f2 : f3;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, fm, acc[t], 0, 0, 0);
             }
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, f2, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, f3, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, f1, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, f2, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, f1, acc[t], 0, 0, 0);
         };
         WF wa, wb;
+        SplitState st;
         wload(0, wa);
-#pragma unroll
-        for (int t = 0; t < NT; t += 2) {
-            wload(t + 1, wb);
-            __builtin_amdgcn_sched_barrier(0);
-            six(t, wa);
-            if (t + 2 < NT) wload(t + 2, wa);
-            __builtin_amdgcn_sched_barrier(0);
-            six(t + 1, wb);
-        }
+        wload(1, wb);
         __builtin_amdgcn_sched_barrier(0);
+        if (tr) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst[1]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t == NT - 1 && tr) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst[2]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int m = 0; m < kPerTile; ++m) {
+                const int slot = t * kPerTile + m;
+                if (t & 1) one(t, wb, m); else one(t, wa, m);
+                if (slot <= kSlots + 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (slot < kSlots) split_slot(slot, f, kc1, wr, Nx, st);
+                    else if (slot == kSlots) fload(kn_, f);          // the raw features are dead: refill them two chunks ahead
+                    else gload(kc1);                                 // W of the next phase AFTER the features: vmcnt retires in order, and the
+                    __builtin_amdgcn_sched_barrier(0);               // next split waits for the features only
+                }
+            }
+            if (t + 2 < NT) { if (t & 1) wload(t + 2, wb); else wload(t + 2, wa); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
+    Pieces pc, pn_;
+    split_feat(fa, 0, true, pc);
+    fload(NPH > 1 ? 1 : 0, fa);
 #pragma unroll 1
     for (int ph = 0; ph < NPH; ++ph) {
         const uint4* wcur = wl[ph & 1];
         uint4* wnext = wl[(ph + 1) & 1];
-        const int pn = ph + 1 < NPH ? ph + 1 : NPH - 1;      // the last phase reloads its own chunks: no branches around the loads
-        gload(pn);
-        __builtin_amdgcn_sched_barrier(0);           // the next phase's loads are issued FIRST: left alone they sink to the barrier
-        chunk(wcur, fa, ph, pn);
+        const int pn = ph + 1 < NPH ? ph + 1 : NPH - 1;      // the last phases reload / re-split their own chunks: no branches around the loads
+        const int p2 = ph + 2 < NPH ? ph + 2 : NPH - 1;
+        const bool tr = a.trace != nullptr && ph == NPH / 2;
+        if (tr) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst[0]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+        chunk(wcur, pc, pn_, fa, pn, p2, ph + 1 < NPH, tr);
+        if (tr) { asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst[3]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
         lstore(wnext);
-        __syncthreads();
+        pc = pn_;
+        if (tr) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst[4]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+        if (!(a.prio & 4)) __syncthreads();          // (probe bit: timing only)
+        if (tr) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst[5]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
     }
+    if (a.trace && lane == 0)
+        for (int k = 0; k < 6; ++k) a.trace[8 * (static_cast<int64_t>(gridDim.x) + 4 * blockIdx.x + wave) + k] = pst[k];
     if constexpr (FUSED) {
         // MODE 5: dfeat[r, :] = dz[r] * acc never reaches memory as such.  The two endpoint reductions of the scorer backward need
         //   d codes[src r, :] += dfeat[r, :] * codes[dst r, :]      and      d codes[dst r, :] += dfeat[r, :] * codes[src r, :].
@@ -1049,6 +1110,9 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
         }
     }
     if constexpr (!BWD) {
+        if ((a.prio & 3) == 1) __builtin_amdgcn_s_setprio(0);
+        if ((a.prio & 3) == 2) __builtin_amdgcn_s_setprio(2);
+        SGS_STAMP(2);
         // ---- forward epilogue (MODE 0 and the paired MODE 3), written for the vector-instruction count: the two waves of a SIMD run it at
         // the same time, so its instructions are not hidden behind anyone's MFMAs.  Per hidden unit and edge: v = (acc + b1) +/- (U[s] - U[d])
         // (acc + b1 shared by the pair), two compares (v > 0; draw >= threshold, the 16-bit draw selected by the compare itself), their AND on
@@ -1154,6 +1218,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
         } else {
             if (live && kh == 0) a.p_out[r] = 1.0f / (1.0f + expf(-(z + a.b2[0])));
         }
+        SGS_STAMP(3);
         return;
     }
     float z = 0.f;
@@ -1919,6 +1984,17 @@ inline int check_common(const char* who, int64_t N, int64_t H, int64_t E, float 
 
 using namespace sgs;
 
+// start-up stagger of the bf16x6 kernels (see the kernel): 80 sleeps of 64 cycles per 32 hidden units ~ half a main loop
+static int g_probe_stagger = -1;                         // >= 0: forced by sgs_edge_score_probe_set
+static int g_probe_prio = 0;
+static unsigned g_stagger_modes = (1u << 0) | (1u << 3); // kernel MODEs that use it
+static unsigned long long* g_probe_trace = nullptr;
+static void bf16x6_launch_knobs(ScoreArgs& a, int mode, int64_t H) {
+    a.stagger = (g_stagger_modes >> mode) & 1u ? (g_probe_stagger >= 0 ? g_probe_stagger : static_cast<int>(80 * (H / 32))) : 0;
+    a.prio = g_probe_prio;
+    a.trace = g_probe_trace;
+}
+
 extern "C" {
 
 size_t sgs_edge_score_workspace_bytes(int64_t N, int64_t H, int64_t E) {
@@ -2000,6 +2076,7 @@ int sgs_edge_score_fwd(const float* codes, const float* U, int64_t N, int64_t H,
         hipLaunchKernelGGL(pack_w1a_bf16x3<false>, dim3(static_cast<unsigned>(cdiv((H / 16) * (H / 32) * 64, kT))), dim3(kT), 0, stream, W1,
                            static_cast<int>(H), Wp16);
         const dim3 grid(static_cast<unsigned>(cdiv(E, 128))), blk(256);       // 4 waves x 32 edges; two workgroups per CU
+        bf16x6_launch_knobs(a, 0, H);
         if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4>), grid, blk, 0, stream, a, Wp16);
         else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4>), grid, blk, 0, stream, a, Wp16);
         SGS_LAUNCH_OK();
@@ -2095,10 +2172,13 @@ static int fwd_bf16x6_impl(const float* codes, const float* U, int64_t N, int64_
     const dim3 grid(static_cast<unsigned>(cdiv(M, 128))), blk(256);
     if (canon) {
         a.dyn_n = dyn_edges_ptr() ? dyn_edges_ptr() + 1 : nullptr;   // word 1 of the registered dims: the live number of canonical edges
-        if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4, 3>), grid, blk, 0, stream, a, Wp16);
+        bf16x6_launch_knobs(a, 3, H);
+        // (probe: prio bit 6 pads the launch with dynamic LDS so that ONE workgroup fits a CU)
+        if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4, 3>), grid, blk, (a.prio & 64) ? 40960 : 0, stream, a, Wp16);
         else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4, 3>), grid, blk, 0, stream, a, Wp16);
     } else {                                                         // every edge runs the contraction (no mates: a directed edge list)
         a.dyn_n = dyn_edges_ptr();
+        bf16x6_launch_knobs(a, 0, H);
         if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4>), grid, blk, 0, stream, a, Wp16);
         else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4>), grid, blk, 0, stream, a, Wp16);
     }
@@ -2179,6 +2259,7 @@ static int bwd_core_impl(const float* codes, const float* U, int64_t N, int64_t 
         b.drop_scale = 1.0f / (1.0f - p_drop); b.drop_thresh = dropout_thresh(p_drop); b.seed = seed; b.epoch = epoch_ptr(); b.site = site;
         b.use_drop = p_drop > 0.f; b.gp = grad_p; b.dv = dv; b.dvbits = dvbits; b.hdz = hdz_part; b.dz = dz; b.feat = feat;
         const dim3 grid(static_cast<unsigned>(cdiv(n_active, 128))), blk(256);
+        bf16x6_launch_knobs(b, 1, H);
         if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4, 1>), grid, blk, 0, stream, b, Wp16);
         else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4, 1>), grid, blk, 0, stream, b, Wp16);
         SGS_LAUNCH_OK();
@@ -2232,6 +2313,7 @@ int sgs_edge_score_bwd_dfeat(const float* dv, int64_t n, int64_t H, const float*
     ScoreArgs a{};
     a.codes = dv; a.n = n; a.H = static_cast<int>(H); a.feat = dfeat;
     const dim3 grid(static_cast<unsigned>(cdiv(n, 128))), blk(256);
+    bf16x6_launch_knobs(a, 2, H);
     if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4, 2>), grid, blk, 0, stream, a, Wp16);
     else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4, 2>), grid, blk, 0, stream, a, Wp16);
     SGS_LAUNCH_OK();
@@ -2259,6 +2341,7 @@ int sgs_edge_score_bwd_dfeat_bits(const uint32_t* dvbits, const float* dz, int64
     ScoreArgs a{};
     a.inbits = dvbits; a.indz = dz; a.n = n; a.H = static_cast<int>(H); a.feat = dfeat;
     const dim3 grid(static_cast<unsigned>(cdiv(n, 128))), blk(256);
+    bf16x6_launch_knobs(a, 4, H);
     if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4, 4>), grid, blk, 0, stream, a, Wp16);
     else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4, 4>), grid, blk, 0, stream, a, Wp16);
     SGS_LAUNCH_OK();
@@ -2378,6 +2461,7 @@ int sgs_edge_score_bwd_dfeat_fused(const uint32_t* dvbits, const float* dz, cons
     ScoreArgs a{};
     a.inbits = dvbits; a.indz = dz; a.n = n; a.H = static_cast<int>(H); a.feat = G; a.codes = codes; a.sd = sd; a.opart = opart;
     const dim3 grid(static_cast<unsigned>(cdiv(n, 128))), blk(256);
+    bf16x6_launch_knobs(a, 5, H);
     if (H == 256) hipLaunchKernelGGL((edge_score_bf16x6_kernel<8, 4, 5>), grid, blk, 0, stream, a, Wp16);
     else          hipLaunchKernelGGL((edge_score_bf16x6_kernel<4, 4, 5>), grid, blk, 0, stream, a, Wp16);
     SGS_LAUNCH_OK();
@@ -2505,6 +2589,18 @@ int sgs_edge_score_epd_reduce(const float* dfeat2, const float* A, int64_t N, in
                        out_eid, active_eid, edge_id_offset, seed_x, site_x, seed_y, site_y, epoch_ptr(), dropout_thresh(p_ep), 1.0f / (1.0f - p_ep),
                        p_ep > 0.f ? 1 : 0, dA);
     SGS_LAUNCH_OK();
+    return SGS_OK;
+}
+
+/* probe knobs of the forward kernel (tools/stagger_probe.py; not part of the product path: both default to 0) */
+int sgs_edge_score_probe_trace(unsigned long long* buf) {
+    g_probe_trace = buf;
+    return SGS_OK;
+}
+int sgs_edge_score_probe_set(int stagger, int prio, uint32_t mode_mask) {
+    g_probe_stagger = stagger;
+    g_probe_prio = prio;
+    g_stagger_modes = mode_mask;
     return SGS_OK;
 }
 
