@@ -23,6 +23,10 @@ ARCH = "gfx950"
 # tests/test_gpu_edge_score.py::test_paired_forward_is_run_to_run_deterministic_at_arxiv_size).
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc"]
+if os.environ.get("SGS_PHASE_PROBE") == "1":       # tools/stagger_trace.py's in-phase stamps (see csrc/edge_score.hip): a library of its own,
+    FLAGS.append("-DSGS_PHASE_PROBE=1")            # loaded only through SGS_LIB_PATH, never the shipped build
+    OBJ = os.path.join(HERE, "build_probe")
+    LIB = os.path.join(HERE, "libsgs_hip_probe.so")
 
 
 def _stale(target, deps):

@@ -806,6 +806,19 @@ __device__ __forceinline__ uint32_t shift_in_bit(uint32_t acc, uint64_t mask) {
     return out;
 }
 
+// Stamps INSIDE a phase of the main loop, and the no-barrier timing probe, exist only in a -DSGS_PHASE_PROBE=1 build (SGS_PHASE_PROBE=1
+// python sgs-gnn_amd/build.py): their branches cut the phase into basic blocks, across which the compiler sinks the operand split out of the
+// MFMA gaps it was placed in.
+#ifndef SGS_PHASE_PROBE
+#define SGS_PHASE_PROBE 0
+#endif
+#if SGS_PHASE_PROBE
+#define SGS_PHASE_STAMP(on, k, pre) do { if (on) asm volatile(pre "s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst[k]) :: "memory"); } while (0)
+#define SGS_PHASE_BARRIER() do { if (!(a.prio & 4)) __syncthreads(); } while (0)
+#else
+#define SGS_PHASE_STAMP(on, k, pre) do { (void)(on); } while (0)
+#define SGS_PHASE_BARRIER() __syncthreads()
+#endif
 #define SGS_STAMP(k) do { if (a.trace && tid == 0) a.trace[8 * blockIdx.x + (k)] = __builtin_readcyclecounter(); } while (0)
 
 template <int NT, int NW, int MODE = 0>
@@ -871,30 +884,37 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
     // MODE 4: the input row is a MASK (bit h of row r); lane (l31, kh) needs bits 16 kc + 8 kh .. + 7 of its row per chunk = byte 2 kc + kh
     const uint8_t* bp = GEMMB ? reinterpret_cast<const uint8_t*>(a.inbits + (live ? r : 0) * (H / 32)) + kh : nullptr;
     struct Feat { float4 xa, xb, ya, yb; uint32_t mb; };
-    // W staging: global -> registers at the head of a phase, registers -> LDS at its end (lane-linear both ways).
-    // (global_load_lds was tried first: next to the ordinary feature loads hipcc 7.2 drains vmcnt(0) before the first ds_read
-    //  of every phase, which serialises the prefetch.)  Named registers, not an array: an array indexed inside the lambdas
-    //  ended up in scratch.
-    uint4 s0, s1, s2, s3, s4, s5;
-    auto gload = [&](int ph) {
-        const uint4* g = Wp16 + static_cast<int64_t>(ph) * CH + tid;
-        s0 = g[0]; s1 = g[TH]; s2 = g[2 * TH];
-        if constexpr (SPT > 3) { s3 = g[3 * TH]; s4 = g[4 * TH]; s5 = g[5 * TH]; }
+    // W staging by LDS-DMA (global_load_lds_dwordx4: no register round trip, no ds_write pass), lane-linear: lane L of wave w moves 16-byte
+    // word k TH + 64 w + L of the chunk to the same word of the stage.  Issued from inline assembly ON PURPOSE: next to a
+    // __builtin_amdgcn_global_load_lds in flight hipcc 7.2 waits vmcnt(0) before every ds_read of the OTHER stage (it cannot tell the
+    // stages apart), which drains the prefetch as soon as it is issued.  The assembly's loads are invisible to the compiler's counters;
+    // every phase retires them itself (s_waitcnt vmcnt(0) ahead of the barrier that publishes the stage).  M0 = the LDS byte address.
+    const uint32_t wl_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) void*)(&wl[0][0])));
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t voff = static_cast<uint32_t>(tid) * 16u;
+    // (M0 is written in the statement that uses it and never restored: nothing else in these kernels reads it -- checked in the ISA.)
+    auto dma_one = [&](int ph, int stage, int k) {
+        const uint4* gb = Wp16 + static_cast<int64_t>(ph) * CH + k * TH;                           // (wave-uniform)
+        const uint32_t ld = wl_lds + static_cast<uint32_t>((stage * CH + k * TH) * 16) + wave_u * 1024u;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" :: "v"(voff), "s"(ld), "s"(gb) : "memory");
     };
-    auto lstore = [&](uint4* w) {
-        w[tid] = s0; w[TH + tid] = s1; w[2 * TH + tid] = s2;
-        if constexpr (SPT > 3) { w[3 * TH + tid] = s3; w[4 * TH + tid] = s4; w[5 * TH + tid] = s5; }
+    auto dma = [&](int ph, int stage) {
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) dma_one(ph, stage, k);
     };
-    auto fload = [&](int kc, Feat& f) {
+    auto fload_x = [&](int kc, Feat& f) {
         if constexpr (GEMMB) { f.mb = bp[2 * kc]; return; }
         f.xa = xp[4 * kc]; f.xb = xp[4 * kc + 1];
-        if (!GEMM) { f.ya = yp[4 * kc]; f.yb = yp[4 * kc + 1]; }
     };
+    auto fload_y = [&](int kc, Feat& f) {
+        if constexpr (!GEMM) { f.ya = yp[4 * kc]; f.yb = yp[4 * kc + 1]; }
+    };
+    auto fload = [&](int kc, Feat& f) { fload_x(kc, f); fload_y(kc, f); };
     struct WF { uint4 q1, q2, q3; };
     Feat fa;
-    gload(0);
+    dma(0, 0);
     fload(0, fa);
-    lstore(wl[0]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     SGS_STAMP(1);
     // Software pipeline over the k-chunks.  Phase ph runs the 6 NT MFMAs of chunk ph on operand pieces that the PREVIOUS phase split, and in
@@ -942,13 +962,18 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
 #pragma unroll
         for (int q = 0; q < kSlots; ++q) split_slot(q, f, kc_, wr, P, st);
     };
-    unsigned long long pst[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // probe: stamps inside phase 8 (a.trace only)
-    auto chunk = [&](const uint4* wcur, const Pieces& C, Pieces& Nx, Feat& f, int kc1, int kn_, bool wr, bool tr) {
+    unsigned long long pst[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // probe: stamps inside one phase (a.trace only)
+    // One phase.  On entry `A` / `B` hold the W fragments of tiles 0 / 1 of the current stage (read at the END of the previous phase, behind
+    // its last tile's MFMAs); fragments of tile t + 2 are read behind the MFMAs of tile t.  Before the LAST tile: the DMA of the next stage
+    // is retired, one barrier publishes it (and says every wave is through reading the stage after next's victim), and the next phase's
+    // first fragments are requested -- A is free (its last user, tile NT - 2, has issued), the odd set alternates between B and `Cn`.
+    auto chunk = [&](const uint4* wcur, const uint4* wnx, int stage_next, WF& A, WF& B, WF& Cn, const Pieces& C, Pieces& Nx, Feat& f, int kc1,
+                     int kn_, bool wr, bool tr) {
         const bf16x8 f1 = __builtin_bit_cast(bf16x8, C.F1), f2 = __builtin_bit_cast(bf16x8, C.F2), f3 = __builtin_bit_cast(bf16x8, C.F3);
-        auto wload = [&](int t, WF& w) {
-            w.q1 = wcur[(t * 3 + 0) * 64 + lane];
-            w.q2 = wcur[(t * 3 + 1) * 64 + lane];
-            w.q3 = wcur[(t * 3 + 2) * 64 + lane];
+        auto wload = [&](const uint4* wsrc, int t, WF& w) {
+            w.q1 = wsrc[(t * 3 + 0) * 64 + lane];
+            w.q2 = wsrc[(t * 3 + 1) * 64 + lane];
+            w.q3 = wsrc[(t * 3 + 2) * 64 + lane];
         };
         constexpr int kPerTile = GEMMB ? 3 : 6;
         auto one = [&](int t, const WF& w, int m) {          // smallest terms first
@@ -961,52 +986,62 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, fm, acc[t], 0, 0, 0);
             }
         };
-        WF wa, wb;
         SplitState st;
-        wload(0, wa);
-        wload(1, wb);
-        __builtin_amdgcn_sched_barrier(0);
-        if (tr) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst[1]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if (t == NT - 1 && tr) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst[2]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+            if (t == NT - 1) {
+                SGS_PHASE_STAMP(tr, 1, "s_waitcnt lgkmcnt(0)\n\t");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   // the next stage has landed (this wave's part)
+                SGS_PHASE_STAMP(tr, 2, "");
+                SGS_PHASE_BARRIER();
+                SGS_PHASE_STAMP(tr, 3, "");
+                wload(wnx, 0, A);
+                wload(wnx, 1, Cn);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int m = 0; m < kPerTile; ++m) {
                 const int slot = t * kPerTile + m;
-                if (t & 1) one(t, wb, m); else one(t, wa, m);
-                if (slot <= kSlots + 1) {
+                if (t & 1) one(t, B, m); else one(t, A, m);
+                // one piece of work per MFMA gap: the split, then the refill of the (now dead) raw features two chunks ahead, then the DMA of
+                // the next phase's W, one 4 KiB instruction per gap (behind the feature loads: vmcnt retires in order)
+                if (slot < kSlots + 2 + SPT) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (slot < kSlots) split_slot(slot, f, kc1, wr, Nx, st);
-                    else if (slot == kSlots) fload(kn_, f);          // the raw features are dead: refill them two chunks ahead
-                    else gload(kc1);                                 // W of the next phase AFTER the features: vmcnt retires in order, and the
-                    __builtin_amdgcn_sched_barrier(0);               // next split waits for the features only
+                    else if (slot == kSlots) fload_x(kn_, f);
+                    else if (slot == kSlots + 1) fload_y(kn_, f);
+                    else dma_one(kc1, stage_next, slot - kSlots - 2);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (t + 2 < NT) { if (t & 1) wload(t + 2, wb); else wload(t + 2, wa); }
+            if (t + 2 < NT) { if (t & 1) wload(wcur, t + 2, B); else wload(wcur, t + 2, A); }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     Pieces pc, pn_;
+    WF wa, wb, wc;
+    {
+        const uint4* w0 = wl[0];
+        wa.q1 = w0[lane]; wa.q2 = w0[64 + lane]; wa.q3 = w0[128 + lane];
+        wb.q1 = w0[192 + lane]; wb.q2 = w0[256 + lane]; wb.q3 = w0[320 + lane];
+    }
     split_feat(fa, 0, true, pc);
     fload(NPH > 1 ? 1 : 0, fa);
+    static_assert(NPH % 2 == 0, "the phase loop is unrolled by two (the odd fragment set and the operand pieces alternate)");
 #pragma unroll 1
-    for (int ph = 0; ph < NPH; ++ph) {
-        const uint4* wcur = wl[ph & 1];
-        uint4* wnext = wl[(ph + 1) & 1];
-        const int pn = ph + 1 < NPH ? ph + 1 : NPH - 1;      // the last phases reload / re-split their own chunks: no branches around the loads
-        const int p2 = ph + 2 < NPH ? ph + 2 : NPH - 1;
+    for (int ph = 0; ph < NPH; ph += 2) {
+        // (the last phases reload / re-split their own chunks: no branches around the loads)
         const bool tr = a.trace != nullptr && ph == NPH / 2;
-        if (tr) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst[0]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-        chunk(wcur, pc, pn_, fa, pn, p2, ph + 1 < NPH, tr);
-        if (tr) { asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst[3]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-        lstore(wnext);
-        pc = pn_;
-        if (tr) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst[4]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-        if (!(a.prio & 4)) __syncthreads();          // (probe bit: timing only)
-        if (tr) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst[5]) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+        SGS_PHASE_STAMP(tr, 0, "");
+        chunk(wl[0], wl[1], 1, wa, wb, wc, pc, pn_, fa, ph + 1, ph + 2 < NPH ? ph + 2 : NPH - 1, true, tr);
+        SGS_PHASE_STAMP(tr, 4, "");
+        chunk(wl[1], wl[0], 0, wa, wc, wb, pn_, pc, fa, ph + 2 < NPH ? ph + 2 : NPH - 1, ph + 3 < NPH ? ph + 3 : NPH - 1, ph + 2 < NPH, false);
     }
+#if SGS_PHASE_PROBE
     if (a.trace && lane == 0)
-        for (int k = 0; k < 6; ++k) a.trace[8 * (static_cast<int64_t>(gridDim.x) + 4 * blockIdx.x + wave) + k] = pst[k];
+        for (int k = 0; k < 5; ++k) a.trace[8 * (static_cast<int64_t>(gridDim.x) + 4 * blockIdx.x + wave) + k] = pst[k];
+#endif
+    __syncthreads();          // (MODE 5 reuses the stages as wave-private tiles; the epilogues' b1 / w2 reads need no more than the first barrier)
     if constexpr (FUSED) {
         // MODE 5: dfeat[r, :] = dz[r] * acc never reaches memory as such.  The two endpoint reductions of the scorer backward need
         //   d codes[src r, :] += dfeat[r, :] * codes[dst r, :]      and      d codes[dst r, :] += dfeat[r, :] * codes[src r, :].

@@ -3,7 +3,11 @@ of one launch, with and without the start-up stagger."""
 import ctypes, json, os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PROBE = os.path.join(ROOT, "sgs-gnn_amd", "libsgs_hip_probe.so")        # SGS_PHASE_PROBE=1 python sgs-gnn_amd/build.py
+if os.path.exists(PROBE):
+    os.environ["SGS_LIB_PATH"] = PROBE
 import sgs_gnn_amd as S
 ops = S.ops
 L = S._lib.lib()
@@ -24,7 +28,7 @@ L.sgs_edge_score_probe_trace.argtypes = [ctypes.c_void_p]
 nwg = 1933
 buf = torch.zeros(nwg * 8 * 5, dtype=torch.int64, device=dev)
 out = {}
-for stagger, prio in ((0, 0), (640, 0), (0, 64)):
+for stagger, prio in ((0, 0), (640, 0), (0, 64), (0, 68)):
     S._lib.check(L.sgs_edge_score_probe_set(stagger, prio, 9))
     run(5)
     torch.cuda.synchronize()
@@ -62,9 +66,10 @@ for stagger, prio in ((0, 0), (640, 0), (0, 64)):
                 if a == b: continue
                 tot += max(0, min(ep[a], ep[b]) - max(ml[a], ml[b]))
             ov.append(tot / max(1, ep[a] - ml[a]))
-    names = ["top->first MFMA (LDS latency)", "first MFMA->last tile (7 tiles of MFMAs + split)", "last tile->W landed", "ds_write", "barrier"]
-    d["phase_breakdown_median_p90"] = {n: [float(np.median(ps[:, k + 1] - ps[:, k])), float(np.percentile(ps[:, k + 1] - ps[:, k], 90))] for k, n in enumerate(names)}
-    d["phase_total"] = float(np.median(ps[:, 5] - ps[:, 0]))
+    if len(ps):
+        names = ["top->before last tile (NT-1 tiles of MFMAs, split, loads)", "wait for the DMA", "barrier", "next fragments + last tile"]
+        d["phase_breakdown_median_p90"] = {n: [float(np.median(ps[:, k + 1] - ps[:, k])), float(np.percentile(ps[:, k + 1] - ps[:, k], 90))] for k, n in enumerate(names)}
+    d["phase_total"] = float(np.median(ps[:, 4] - ps[:, 0])) if len(ps) else None
     d["main_loop_overlap_frac_with_cu_mates"] = float(np.mean(ov))
     d["workgroups_per_cu"] = float(len(cu) / len(np.unique(cu)))
     d["clock_span"] = int(en.max())
