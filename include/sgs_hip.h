@@ -194,6 +194,16 @@ int sgs_graph_filter(const int32_t* pin_ptr, const int32_t* pin_src, const int32
                      const int64_t* sampled_eid, int64_t q, int32_t* in_ptr, int32_t* in_src, int32_t* in_eid, int32_t* out_ptr,
                      int32_t* out_dst, int32_t* out_eid, int32_t* loop_eid, void* ws, size_t ws_bytes, sgs_stream_t stream);
 
+/* sgs_graph_build for an edge list that is SORTED BY SOURCE (what a draw over a row-sorted edge list emits; the reference's loaders all
+ * produce row-sorted lists, and sampling.py keeps the order: edge_index[:, mask]).  The out-CSR is then the list itself; the in-CSR is ONE
+ * stable radix sort of (dst, (src, edge id)) -- at whole-graph scale (config 5: q = 22.9 M drawn edges of 114.6 M) this replaces
+ * sgs_graph_filter's passes over the PARENT's CSR.  Same arrays as sgs_graph_build.  `unsorted` (device word, may be NULL): set to 1 if
+ * the list turns out not to be sorted by source (the arrays are then meaningless), 0 otherwise. */
+size_t sgs_graph_build_src_sorted_workspace_bytes(int64_t n_edges, int64_t N);
+int sgs_graph_build_src_sorted(const int64_t* edge_index, int64_t n_edges, int64_t N, int32_t* in_ptr, int32_t* in_src, int32_t* in_eid,
+                               int32_t* out_ptr, int32_t* out_dst, int32_t* out_eid, int32_t* loop_eid, int32_t* unsorted, void* ws,
+                               size_t ws_bytes, sgs_stream_t stream);
+
 /* gcn_norm forward (PyG gcn_norm, add_self_loops=True, flow source_to_target):
  *   loopw_i = w[loop_eid_i] or 1;  deg_i = loopw_i + sum_{e=(j->i), j!=i} w_e;  dis = deg^-1/2 (inf -> 0)
  *   what_in[k]  = dis[src] * w * dis[dst] in dst-CSR order,  what_out[k] the same in src-CSR order

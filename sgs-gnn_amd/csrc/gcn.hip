@@ -12,6 +12,10 @@
 
 namespace sgs {
 size_t graph_sort_workspace_bytes(int64_t n, int64_t N);
+size_t graph_src_sorted_workspace_bytes(int64_t n, int64_t N);
+int graph_build_src_sorted(const int64_t* ei, int64_t n, int64_t N, int32_t* in_ptr, int32_t* in_src, int32_t* in_eid, int32_t* out_ptr,
+                           int32_t* out_dst, int32_t* out_eid, int32_t* loop_eid, int32_t* unsorted_flag, void* ws, size_t ws_bytes,
+                           hipStream_t stream);
 int graph_build_by_sort(const int64_t* ei, int64_t n, int64_t N, int32_t* in_ptr, int32_t* in_src, int32_t* in_eid, int32_t* out_ptr,
                         int32_t* out_dst, int32_t* out_eid, int32_t* loop_eid, void* ws, size_t ws_bytes, hipStream_t stream);
 }
@@ -1034,6 +1038,23 @@ int sgs_graph_build(const int64_t* edge_index, int64_t n_edges, int64_t N, int32
     }
     SGS_LAUNCH_OK();
     return SGS_OK;
+}
+
+size_t sgs_graph_build_src_sorted_workspace_bytes(int64_t n_edges, int64_t N) {
+    return graph_src_sorted_workspace_bytes(n_edges < 0 ? 0 : n_edges, N < 0 ? 0 : N);
+}
+
+int sgs_graph_build_src_sorted(const int64_t* edge_index, int64_t n_edges, int64_t N, int32_t* in_ptr, int32_t* in_src, int32_t* in_eid,
+                               int32_t* out_ptr, int32_t* out_dst, int32_t* out_eid, int32_t* loop_eid, int32_t* unsorted, void* ws,
+                               size_t ws_bytes, sgs_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    SGS_REQUIRE(n_edges >= 0 && N >= 0 && n_edges < (int64_t(1) << 31) && N < (int64_t(1) << 31), SGS_EINVAL,
+                "sgs_graph_build_src_sorted: sizes out of range (n_edges=%lld N=%lld)", (long long)n_edges, (long long)N);
+    if (N == 0) return SGS_OK;
+    SGS_REQUIRE(in_ptr && out_ptr && loop_eid && (n_edges == 0 || (edge_index && in_src && in_eid && out_dst && out_eid)), SGS_EINVAL,
+                "sgs_graph_build_src_sorted: null pointer");
+    SGS_REQUIRE(ws && (reinterpret_cast<uintptr_t>(ws) & 255) == 0, SGS_EINVAL, "sgs_graph_build_src_sorted: workspace must be 256-B aligned");
+    return graph_build_src_sorted(edge_index, n_edges, N, in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, loop_eid, unsorted, ws, ws_bytes, stream);
 }
 
 size_t sgs_graph_filter_workspace_bytes(int64_t E_parent, int64_t N) {

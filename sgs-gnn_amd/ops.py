@@ -357,6 +357,9 @@ class Graph:
                                      ws.data_ptr(), ws.numel(), _stream()), "sgs_graph_build")
 
 
+_SORT_SUBGRAPH_EDGES = int(os.environ.get("SGS_SORT_SUBGRAPH_EDGES", 1 << 22))     # drawn edges from which get_subgraph sorts instead of filtering
+
+
 def get_subgraph(parent_edge_index: torch.Tensor, N: int, sample, eid=None) -> Graph:
     """CSR of a drawn subgraph (`sample` = SampleResult of a draw over `parent_edge_index`) squeezed out of the parent's cached
     CSR (sgs_graph_filter): no atomics and no per-row sort, identical arrays to Graph(sample.edge_index).  The result is cached
@@ -375,6 +378,18 @@ def get_subgraph(parent_edge_index: torch.Tensor, N: int, sample, eid=None) -> G
         offs.append(offs[-1] + ((z + 63) & ~63))
     buf = torch.empty(offs[-1], dtype=torch.int32, device=ei.device)
     (g.in_ptr, g.out_ptr, g.in_src, g.in_eid, g.out_dst, g.out_eid, g.loop_eid) = (buf[offs[i]:offs[i] + sizes[i]] for i in range(7))
+    if n >= _SORT_SUBGRAPH_EDGES and src_sorted(parent_edge_index):
+        # whole-graph scale: one packed radix sort of the DRAWN edges instead of two passes over the parent's CSR (sgs_graph_build_src_sorted)
+        ws = workspace(L.sgs_graph_build_src_sorted_workspace_bytes(n, N), ei.device)
+        _lib.check(L.sgs_graph_build_src_sorted(_ptr(ei), n, N, _ptr(g.in_ptr), _ptr(g.in_src), _ptr(g.in_eid), _ptr(g.out_ptr), _ptr(g.out_dst),
+                                                _ptr(g.out_eid), _ptr(g.loop_eid), None, ws.data_ptr(), ws.numel(), _stream()),
+                   "sgs_graph_build_src_sorted")
+        try:
+            ei._sgs_graph = g
+            ei._sgs_graph_version = ei._version
+        except Exception:
+            pass
+        return g
     ws = workspace(L.sgs_graph_filter_workspace_bytes(parent.n_edges, N), ei.device)
     _lib.check(L.sgs_graph_filter(_ptr(parent.in_ptr), _ptr(parent.in_src), _ptr(parent.in_eid), _ptr(parent.out_ptr), _ptr(parent.out_dst),
                                   _ptr(parent.out_eid), parent.n_edges, N, _ptr(_u8(sample.mask)), _ptr(sample.eid if eid is None else eid, torch.int64), n,

@@ -120,6 +120,40 @@ def test_reddit_scale_node_count_generic_paths():
     assert torch.equal(r.edge_index[:, :1000], ei[:, r.mask][:, :1000])
 
 
+def test_get_subgraph_sort_path_at_whole_graph_scale_equals_build():
+    """q >= 2^22 drawn edges of a source-sorted parent: get_subgraph sorts the drawn edges (sgs_graph_build_src_sorted) -- same arrays as
+    sgs_graph_build of the drawn list (itself the two-sort path at this size) and as the filter path."""
+    import sgs_gnn_amd as S
+    ops = S.ops
+    N, E, q = 20000, 12_000_000, 4_500_001
+    g = torch.Generator(device=DEV).manual_seed(4)
+    ei = torch.randint(0, N, (2, E), device=DEV, generator=g)
+    ei[:, :7] = ei[0, :7]
+    ei = ei[:, torch.argsort(ei[0] * N + ei[1])].contiguous()
+    p = torch.rand(E, device=DEV, generator=g)
+    r = ops.sample_topq(ops.SAMPLE_LEARNED, p, None, 0.0, q, ei, seed=3, stream_id=1)
+    assert q >= ops._SORT_SUBGRAPH_EDGES and ops.src_sorted(ei)
+    child = ops.get_subgraph(ei, N, r)
+    ref = ops.Graph(r.edge_index.clone(), N)
+    torch.cuda.synchronize()
+    for name in ("in_ptr", "out_ptr", "in_src", "in_eid", "out_dst", "out_eid", "loop_eid"):
+        a, b = getattr(child, name), getattr(ref, name)
+        n = q if name in ("in_src", "in_eid", "out_dst", "out_eid") else a.numel()
+        assert torch.equal(a[:n], b[:n]), name
+    old = ops._SORT_SUBGRAPH_EDGES
+    ops._SORT_SUBGRAPH_EDGES = 1 << 40
+    try:
+        r2 = ops.sample_topq(ops.SAMPLE_LEARNED, p, None, 0.0, q, ei, seed=3, stream_id=1)
+        filt = ops.get_subgraph(ei, N, r2)
+    finally:
+        ops._SORT_SUBGRAPH_EDGES = old
+    torch.cuda.synchronize()
+    for name in ("in_ptr", "out_ptr", "in_src", "in_eid", "out_dst", "out_eid", "loop_eid"):
+        a, b = getattr(child, name), getattr(filt, name)
+        n = q if name in ("in_src", "in_eid", "out_dst", "out_eid") else a.numel()
+        assert torch.equal(a[:n], b[:n]), name
+
+
 def test_graph_filter_bitmask_path_equals_build():
     """sgs_graph_filter on a parent of >= 2^23 edges (bit-mask lookups) == sgs_graph_build of the drawn edge list."""
     import sgs_gnn_amd as S

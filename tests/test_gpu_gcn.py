@@ -242,6 +242,74 @@ def test_graph_filter_equals_build_of_the_compacted_edges(pkg, N, E, q):
     assert ops.get_graph(r.edge_index, N) is child               # cached on the drawn edge list
 
 
+@pytest.mark.parametrize("N,E", [(1, 0), (5, 3), (50, 700), (1013, 100000), (3, 30000), (40000, 90000)])
+def test_graph_build_src_sorted_equals_graph_build(pkg, N, E):
+    """sgs_graph_build_src_sorted (out-CSR = the list itself, in-CSR = one packed radix sort) == sgs_graph_build on source-sorted edge
+    lists with self loops, duplicate edges and empty rows; the `unsorted` word reports a list that breaks the precondition."""
+    ops, L = pkg.ops, pkg._lib.lib()
+    ei, g = rand_graph(N, E, N + E)
+    if E:
+        ei = ei[:, torch.argsort(ei[0], stable=True)]
+    ei = ei.contiguous().to(DEV)
+    ref = ops.Graph(ei, N)
+    ne = max(E, 1)
+    arr = {k: torch.full((n_,), -7, dtype=torch.int32, device=DEV) for k, n_ in (("in_ptr", N + 1), ("out_ptr", N + 1), ("in_src", ne), ("in_eid", ne),
+                                                                                 ("out_dst", ne), ("out_eid", ne), ("loop_eid", N))}
+    flag = torch.full((1,), 5, dtype=torch.int32, device=DEV)
+    ws = ops.workspace(L.sgs_graph_build_src_sorted_workspace_bytes(E, N), ei.device)
+
+    def build(e):
+        pkg._lib.check(L.sgs_graph_build_src_sorted(e.data_ptr(), E, N, arr["in_ptr"].data_ptr(), arr["in_src"].data_ptr(), arr["in_eid"].data_ptr(),
+                                                    arr["out_ptr"].data_ptr(), arr["out_dst"].data_ptr(), arr["out_eid"].data_ptr(),
+                                                    arr["loop_eid"].data_ptr(), flag.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()), "src_sorted")
+        torch.cuda.synchronize()
+
+    build(ei)
+    assert int(flag) == 0
+    for name, a in arr.items():
+        n = E if name in ("in_src", "in_eid", "out_dst", "out_eid") else a.numel()
+        assert torch.equal(a[:n], getattr(ref, name)[:n]), name
+    if E > 100 and N > 1:
+        bad = ei.flip(1).contiguous()
+        if not bool((bad[0, 1:] >= bad[0, :-1]).all()):
+            build(bad)
+            assert int(flag) == 1
+
+
+def test_get_subgraph_sorts_the_drawn_edges_above_its_threshold(pkg, monkeypatch):
+    """get_subgraph's whole-graph path (one sort of the drawn edges) against its filter path, on the same draw."""
+    ops = pkg.ops
+    N, E, q = 1013, 120000, 40000
+    g = torch.Generator().manual_seed(5)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[:, :5] = ei[0, :5]
+    ei = ei[:, torch.argsort(ei[0] * N + ei[1], stable=True)].contiguous().to(DEV)
+    p = torch.rand(E, generator=g).to(DEV)
+    r = ops.sample_topq(ops.SAMPLE_LEARNED, p, None, 0.0, q, ei, seed=3, stream_id=1)
+    filt = ops.get_subgraph(ei, N, r)
+    monkeypatch.setattr(ops, "_SORT_SUBGRAPH_EDGES", 1000)
+    r2 = ops.sample_topq(ops.SAMPLE_LEARNED, p, None, 0.0, q, ei, seed=3, stream_id=1)
+    assert torch.equal(r.edge_index, r2.edge_index)
+    srt = ops.get_subgraph(ei, N, r2)
+    torch.cuda.synchronize()
+    assert srt is not filt
+    for name in ("in_ptr", "out_ptr", "in_src", "in_eid", "out_dst", "out_eid", "loop_eid"):
+        a, b = getattr(srt, name), getattr(filt, name)
+        n = q if name in ("in_src", "in_eid", "out_dst", "out_eid") else a.numel()
+        assert torch.equal(a[:n], b[:n]), name
+    # an UNSORTED parent keeps the filter (the sort path's precondition does not hold)
+    perm = torch.randperm(E, generator=g).to(DEV)
+    eu = ei[:, perm].contiguous()
+    r3 = ops.sample_topq(ops.SAMPLE_LEARNED, p, None, 0.0, q, eu, seed=3, stream_id=1)
+    child = ops.get_subgraph(eu, N, r3)
+    ref = ops.Graph(r3.edge_index.clone(), N)
+    torch.cuda.synchronize()
+    for name in ("in_ptr", "out_ptr", "in_src", "in_eid", "out_dst", "out_eid", "loop_eid"):
+        a, b = getattr(child, name), getattr(ref, name)
+        n = q if name in ("in_src", "in_eid", "out_dst", "out_eid") else a.numel()
+        assert torch.equal(a[:n], b[:n]), name
+
+
 def test_sparse_feature_products_match_dense_and_replay_through_the_slots():
     """ops.feature_csr: bag-of-words node features (CitationFull-Cora: 0.7 % dense) run the first layers' x W^T and d W = d Y^T x as SpMMs
     over nnz(x).  (1) both products against the dense ones; (2) a layer's gradients with the sparse path on and off; (3) graph mode: the
