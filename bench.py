@@ -445,12 +445,22 @@ def run_s2(a, S, device):
         learned += r[2]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    # dominant kernel here: the node GEMM X W^T [N,F] x [F,H] (library GEMM through torch, hipBLASLt), run for the scorer's and the
-    # GNN's first layer every step
+    # dominant kernel here (profiles/r03_s2_kernel_stats.csv): the node-level product x W^T of the first GCN layers over the NON-ZEROS of the
+    # 0.7 %-dense bag-of-words rows (ops.FeatCSR -> sgs_spmm_csr gathering rows of W^T), four launches per step; HBM-bound gather, priced per
+    # SURVEY.md 8d's SpMM row: per nnz 4 B column + 4 B value + 4 H B gathered row; 4 H N B output; 8 (N + 1) B row pointers
+    ops = S.ops
     W = model.gcn1.lin.weight.detach()
-    ms = _hip_time(lambda: torch.mm(b.x, W.t()), 20)
-    flops = 2.0 * b.x.shape[0] * Fin * HID
-    ach = flops / (ms * 1e-3) / 1e12
+    fc = ops.feature_csr(b.x, build=True)
+    if fc is None:
+        raise SystemExit("S2: the feature matrix did not take the sparse path")
+    with torch.no_grad():
+        ms = _hip_time(lambda: ops._x_wt(b.x, W), 20)                     # (includes the [F, H] transpose copy of W, as every step does)
+        Wt = W.t().contiguous()
+        ms_k = _hip_time(lambda: ops._spmm(Wt, fc.ptr, fc.col, fc.val, None, None, ops.ACT_NONE, 0.0, 0, 0, fc.N, HID, fc.nnz), 20)
+        ms_dense = _hip_time(lambda: torch.mm(b.x, W.t()), 5)
+    Nn = b.x.shape[0]
+    alg = fc.nnz * (8 + 4 * HID) + 4 * HID * Nn + 8 * (Nn + 1)
+    compulsory = fc.nnz * 8 + 4 * HID * Fin + 4 * HID * Nn + 8 * (Nn + 1)   # W^T read once instead of once per non-zero
     rec = {"metric": METRIC, "value": round(q * a.steps / dt, 1), "unit": "sampled edges/s", "steps_per_s": round(a.steps / dt, 3), "n_gpus": 1,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -458,9 +468,17 @@ def run_s2(a, S, device):
                                   "epoch (main.py:67), hybrid pipeline, EdgeProbGCN scorer, conditional gate, reg1+reg2, dropout 0.3, Adam x2",
                       "hipgraph_replay": bool(a.hipgraph)},
            "conditional_updates": learned, "capture_s": round(cap, 3),
-           "roofline": {"bound": "mfma", "kernel": "node GEMM X W^T [19793 x 8710] x [8710 x 256] (hipBLASLt via torch.mm, fp32)",
-                        "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
-                        "traffic": None, "ms_per_launch": round(ms, 4)}}
+           "roofline": {"bound": "hbm", "kernel": f"sparse-feature node product x W^T over nnz(x) = {fc.nnz} (sgs_spmm_csr, D = {HID}; "
+                                                  "spmm_csr_rowblock<4, 4>): the step's largest kernel, 4 launches per step",
+                        "achieved": round(compulsory / (ms_k * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(compulsory / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "ms_per_launch": round(ms_k, 4),
+                        "algorithmic_bytes": compulsory, "uncached_gather_bytes": alg,
+                        "uncached_gather_GBps": round(alg / (ms_k * 1e-3) / 1e9, 1),
+                        "ms_with_weight_transpose": round(ms, 4), "ms_dense_library_gemm": round(ms_dense, 4),
+                        "note": "achieved = SURVEY 8d's COMPULSORY figure (CSR of x, W^T and the output once each): 39 MB per launch, so the "
+                                "kernel is latency-, not HBM-bound at this size.  uncached_gather_GBps counts the gathered W^T row once per "
+                                "non-zero (8d's upper figure; the 8.9 MB table is L2 / Infinity-Cache resident: gather bandwidth, above the "
+                                "HBM peak).  The dense [N, F] x [F, H] library GEMM this replaces: ms_dense_library_gemm"}}
     if not a.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline(b.to("cpu"), nfeat=Fin, ncls=C, q=q, warm=1, timed=3)
     return rec
@@ -490,9 +508,12 @@ def run_s4(a, S, device):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     steps = epochs * parts
-    # K8 (GAT attention + aggregation over the drawn graph, nnz = q + n): bandwidth-bound gather; algorithmic bytes per SURVEY 8d
+    # dominant kernels (profiles/r03_s4_kernel_stats.csv): the straight-through pipeline scores and back-propagates ALL E_b candidate edges, so
+    # the step is the scorer -- forward (paired bf16x6 loop, MFMA-bound) and the dense backward over every edge.  `roofline` prices the
+    # forward, the largest MFMA kernel, exactly as the S3 line does; `gat_layer` keeps the K8 figure of round 2 (HBM-bound gather).
     ops = S.ops
     b0 = pool[0]
+    roof = scorer_roofline(S, model, max(pool, key=lambda b: b.edge_index.shape[1]), a.score_variant, n_nodes=n, hid=HID, alts=False)
     smp = ops.sample_topq(ops.SAMPLE_PRIOR, b0.prob, None, 0.0, q, b0.edge_index, seed=1, stream_id=1, want_p=False)
     graph = ops.get_subgraph(b0.edge_index, n, smp)
     xl = torch.randn(n, HID, device=device)
@@ -502,6 +523,11 @@ def run_s4(a, S, device):
         ms = _hip_time(lambda: ops.gat_aggregate(xl, a_s, a_d, bias, graph, 0.2, 0.3, 7, 16, ops.ACT_RELU_DROPOUT, 0.3, 7, 32), 20)
     nnz = q + n
     alg = nnz * (4 + 4 + 4 * HID + 8) + 4 * HID * n + 8 * (n + 1)           # col + weight + gathered row + 2 node scalars per nnz; output; row pointers
+    roof["gat_layer"] = {"bound": "hbm", "kernel": "GAT layer forward over the drawn graph: sgs_gat_alpha_fwd + sgs_spmm_csr (D=256, nnz=q+n)",
+                         "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms_per_launch": round(ms, 4), "algorithmic_bytes": alg,
+                         "note": "gathered rows counted per nnz (uncached upper figure, SURVEY 8d); the 35 MB feature table is L2 / "
+                                 "Infinity-Cache resident"}
     rec = {"metric": METRIC, "value": round(q * steps / dt, 1), "unit": "sampled edges/s", "steps_per_s": round(steps / dt, 3), "n_gpus": 1,
            "steps": steps, "warmup": a.warmup, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -509,11 +535,7 @@ def run_s4(a, S, device):
                                   f"q={q}, --GNN GAT (heads 1), straight_through pipeline, EdgeProbGCN scorer, conditional gate, dropout 0.3, Adam x2",
                       "hipgraph_replay": bool(a.hipgraph)},
            "conditional_updates": learned, "capture_s": round(cap, 3),
-           "roofline": {"bound": "hbm", "kernel": "GAT layer forward over the drawn graph: sgs_gat_alpha_fwd + sgs_spmm_csr (D=256, nnz=q+n)",
-                        "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "ms_per_launch": round(ms, 4),
-                        "algorithmic_bytes": alg, "note": "gathered rows counted per nnz (uncached upper figure, SURVEY 8d); the 35 MB "
-                                                          "feature table is L2 / Infinity-Cache resident"}}
+           "roofline": roof}
     return rec
 
 

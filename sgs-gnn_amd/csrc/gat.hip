@@ -195,15 +195,37 @@ __global__ void __launch_bounds__(kT) gat_scores_bwd(const float* __restrict__ x
     }
 }
 
-__global__ void __launch_bounds__(kT) gat_scores_bwd_finish(const float* __restrict__ part, int nwg, int64_t D, float* __restrict__ datt_s,
-                                                           float* __restrict__ datt_d) {
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x;
-    if (c >= 2 * D) return;
+// d att = sum over the workgroups' partial rows, fixed order: 64 columns x 16 row groups per workgroup (row group g takes partials g, g + 16,
+// ... with four independent running sums; the groups are then added in order).  One thread per column walking all `nwg` rows was a chain of
+// 530 dependent loads at arxiv-year's size: 89 us for 1 MB.
+__global__ void __launch_bounds__(1024) gat_scores_bwd_finish(const float* __restrict__ part, int nwg, int64_t D, float* __restrict__ datt_s,
+                                                             float* __restrict__ datt_d) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * 64 + lane;             // column of the concatenated [2 D] vector
+    const bool ok = c < 2 * D;
     const int which = c >= D ? 1 : 0;
     const int64_t cc = which ? c - D : c;
-    float acc = 0.f;
-    for (int w = 0; w < nwg; ++w) acc += part[(static_cast<int64_t>(w) * 2 + which) * D + cc];
-    (which ? datt_d : datt_s)[cc] = acc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (ok) {
+        const float* col = part + static_cast<int64_t>(which) * D + cc;
+        int w = g;
+        for (; w + 48 < nwg; w += 64) {
+            a0 += col[static_cast<int64_t>(w) * 2 * D];
+            a1 += col[static_cast<int64_t>(w + 16) * 2 * D];
+            a2 += col[static_cast<int64_t>(w + 32) * 2 * D];
+            a3 += col[static_cast<int64_t>(w + 48) * 2 * D];
+        }
+        for (; w < nwg; w += 16) a0 += col[static_cast<int64_t>(w) * 2 * D];
+    }
+    red[g][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (g == 0 && ok) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += red[k][lane];
+        (which ? datt_d : datt_s)[cc] = acc;
+    }
 }
 
 }  // namespace
@@ -297,7 +319,7 @@ int sgs_gat_scores_bwd(const float* xl, int64_t N, int64_t D, const float* att_s
         hipLaunchKernelGGL((gat_scores_bwd<true>), dim3(nwg), dim3(kT), 0, stream, xl, N, D, att_src, att_dst, g_src, g_dst, dxl, part, rp);
     else
         hipLaunchKernelGGL((gat_scores_bwd<false>), dim3(nwg), dim3(kT), 0, stream, xl, N, D, att_src, att_dst, g_src, g_dst, dxl, part, rp);
-    hipLaunchKernelGGL(gat_scores_bwd_finish, dim3(static_cast<unsigned>((2 * D + kT - 1) / kT)), dim3(kT), 0, stream, part, nwg, D, datt_src, datt_dst);
+    hipLaunchKernelGGL(gat_scores_bwd_finish, dim3(static_cast<unsigned>((2 * D + 63) / 64)), dim3(1024), 0, stream, part, nwg, D, datt_src, datt_dst);
     SGS_LAUNCH_OK();
     return SGS_OK;
 }
