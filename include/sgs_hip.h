@@ -476,6 +476,10 @@ int sgs_gemm_tn_mask_supported(int64_t K, int64_t M, int64_t N);
 int sgs_gemm_tn_mask_gather(const uint32_t* Abits, const float* dz, const float* rowscale, float scale, const float* codes, int64_t codes_rows,
                             const int32_t* sd, int64_t K, int64_t M, int64_t N, float* C, int64_t ldc, float* colsum_A, float* dz_sum, float* C_raw,
                             float* colsum_raw, void* ws, size_t ws_bytes, sgs_stream_t stream);
+/* A/B switch of sgs_gemm_tn_mask_gather (tests, tools): shared = 1 (default) the shared-operand kernel -- the four waves of a K-group gather,
+ * multiply and split a step's rows ONCE and exchange the operand fragments through LDS --, 0 the per-wave-slice kernel of round 2 (also what
+ * shapes the shared kernel does not serve fall back to).  slabs > 0 forces the number of K-slices (workgroups per column group). */
+void sgs_gemm_tn_set_gather_variant(int shared, int slabs);
 int sgs_gemm_tn_mask(const uint32_t* Abits, const float* dz, const float* rowscale, float scale, const float* B, int64_t K, int64_t M, int64_t N,
                      float* C, int64_t ldc, float* colsum_A, float* dz_sum, float* C_raw, float* colsum_raw, void* ws, size_t ws_bytes,
                      sgs_stream_t stream);

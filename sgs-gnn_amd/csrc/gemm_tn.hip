@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce(const float* __restrict__ 
                                                       int N = 0, int64_t ldc = 0, const float* __restrict__ rowscale = nullptr,
                                                       float scale = 1.f, const float* __restrict__ dzpart = nullptr, int nz = 0,
                                                       float* __restrict__ dzsum = nullptr, float* __restrict__ Craw = nullptr,
-                                                      float* __restrict__ csraw = nullptr) {
+                                                      float* __restrict__ csraw = nullptr, int csplit = 0) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (i >= mn) {
         const int64_t c = i - mn;                       // trailing threads: the column sums of A, slices in the same fixed order
@@ -123,7 +123,22 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce(const float* __restrict__ 
         }
         if (colsum && c < M) {
             float acc = 0.f;
-            for (int s = 0; s < ksplit; ++s) acc += cpart[static_cast<int64_t>(s) * M + c];
+            const int ncs = csplit > 0 ? csplit : ksplit;     // (the shared-operand kernel writes NG column-sum rows per slab)
+            if (csplit > 0) {
+                // many rows: eight loads in flight, eight running sums joined in a fixed tree (one dependent load per row was 50 us at 256 rows)
+                float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                int s = 0;
+                for (; s + 8 <= ncs; s += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = cpart[static_cast<int64_t>(s + j) * M + c];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a8[j] += v[j];
+                }
+                for (; s < ncs; ++s) a8[0] += cpart[static_cast<int64_t>(s) * M + c];
+                acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+            } else
+            for (int s = 0; s < ncs; ++s) acc += cpart[static_cast<int64_t>(s) * M + c];
             if (csraw) csraw[c] = acc;                  // (the sums before the row factor: a term of d fc2.weight)
             colsum[c] = rowscale ? acc * (rowscale[c] * scale) : acc;
         }
@@ -541,6 +556,254 @@ __global__ void __launch_bounds__(64 * NW) gemm_tn_tall_bf16x6(const float* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The scorer's weight gradient, shared-operand form (round 3):  T[h, c] = sum_k dz[k] mask[k, h] (codes[src k, c] codes[dst k, c]).
+// gemm_tn_tall_bf16x6<.., true, true> gives every WAVE its own K-slice and a 128 x 64 tile, so every wave gathers, multiplies and splits
+// all 16 rows x 64 columns of a step itself (~300 vector instructions and 40 loads per 24 MFMAs, one wave per SIMD: 84 us at K = 100 000
+// where the matrix work is 16 us; counters: VALU-bound at 55 % activity, waiting on its gathers the rest of the time).  Here the four waves
+// of a K-group walk the SAME rows and share the operands through LDS:
+//   * wave w gathers / multiplies / splits rows 8 g + 2 w, + 1 of the step only (8 loads, two split3 per lane) and writes its dword of
+//     every B fragment ([u][piece][lane][m = w]); all four read whole fragments back (six ds_read_b128 per step);
+//   * the step's 16 x M / 32 mask words and 16 dz go through LDS once (coalesced), an A fragment is two broadcast ds_read_b128 + 11 vector
+//     instructions per tile (bit pairs of two rows multiplied by 0x3F80 as one u24 product);
+//   * a wave owns 64 (M = 256) or 32 (M = 128) hidden units x 64 columns: 2 MT accumulator tiles, 6 MT MFMAs per step against ~100 vector
+//     instructions -- balanced, at half the registers, so two or three waves share a SIMD and cover each other's gathers.
+// Two K-groups per workgroup (8 waves) on adjacent halves of the workgroup's K-slice, summed through LDS at the end: one slab per
+// workgroup.  Three LDS stages, ONE barrier per step: step i + 1 is written while step i is multiplied; the endpoints of step i + 3 and
+// the rows of step i + 2 are in flight.  Column sums of dz * mask (d b1) are split over the NG = N / 64 column groups (rows 8 / NG each).
+// Fixed order throughout: run-to-run deterministic; NOT bit-identical to the per-wave-slice kernel (another summation order).
+template <int MT, int NG>
+__global__ void __launch_bounds__(512) gemm_tn_maskfeat(const uint32_t* __restrict__ Abits, const float* __restrict__ dz,
+                                                        const float* __restrict__ codes, const int2* __restrict__ sd, int64_t K, int N,
+                                                        float* __restrict__ slab, float* __restrict__ cpart, float* __restrict__ dzpart) {
+    constexpr int M = 128 * MT, WPR = M / 32;
+    constexpr int kBst = 2 * 3 * 64 * 4;                    // dwords of B fragments per stage: [u][piece][lane][m]
+    constexpr int kMst = WPR * 16;                          // mask words per stage: [word][row]
+    constexpr int kStage = kBst + kMst + 16;                // + 16 dz
+    extern __shared__ uint32_t lds[];                       // [2 K-groups][3 stages][kStage]; reused for the K-group sum
+    const int lane = threadIdx.x & 63, g = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kg = wave >> 2, w = wave & 3;
+    const int ng = blockIdx.x, n0 = ng * 64, slab_id = blockIdx.y;             // (gridDim.x == NG)
+    const int64_t per = (((K + gridDim.y - 1) / gridDim.y) + 63) & ~int64_t(63);        // workgroup slice: two halves of an EVEN number of whole steps
+    const int64_t kb = static_cast<int64_t>(slab_id) * per + kg * (per >> 1);
+    const int64_t ke = (kb + (per >> 1) < K) ? kb + (per >> 1) : K;                        // (ke <= kb: an empty trailing half)
+    const int nsteps = static_cast<int>(per >> 5);                                          // the same for every K-group (barriers)
+    const int lim = static_cast<int>(ke - kb);
+    uint32_t* st0 = lds + kg * (3 * kStage);
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+    float cs[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) cs[t] = 0.f;
+    float dzs = 0.f;
+    const bool want_cs = cpart != nullptr, want_dz = dzpart != nullptr && ng == 0;
+    constexpr int rpg = 8 / NG;                              // rows (of every 8) whose dz * mask this column group sums; NG in {1, 2, 4, 8}
+    // this lane's two rows of a step: 8 g + 2 w (+ 1); its staging duty: mask word (tid_g % WPR) of row (tid_g / WPR), dz of row lane
+    const int tid_g = threadIdx.x & 255;
+    const int srow = (tid_g / WPR) & 15, sword = tid_g % WPR;
+    const bool stage_mask = tid_g < 16 * WPR, stage_dz = w == 3 && lane < 16;
+    // Every load is UNCONDITIONAL on a clamped row (a load under a branch, or arithmetic on its result next to it, makes the compiler wait
+    // for it on the spot -- with the dependent gather behind it that was two exposed memory round trips per step); rows past the half are
+    // neutralised when the step is published, through dz = 0.  Addresses are a wave-uniform base (the half's first row) plus a 32-bit
+    // offset: scalar-base loads, no 64-bit vector address arithmetic.
+    struct S1 { int2 ea, eb; float da, db; uint32_t mw; float dl; };
+    struct S2 { float2 as, ad, bs, bd; float da, db; uint32_t mw; float dl; };
+    const int64_t kbase = lim > 0 ? kb : 0;                   // (an empty half reads row 0, with dz = 0)
+    const int2* sdb = sd + kbase;
+    const float* dzb = dz + kbase;
+    const uint32_t* abb = Abits + kbase * WPR;
+    const int last = lim > 0 ? lim - 1 : 0;
+    auto clampr = [&](int rel) { return static_cast<uint32_t>(max(min(rel, last), 0)); };
+    const uint32_t coff = static_cast<uint32_t>(n0 + 2 * l31);
+    auto load_idx = [&](int step) {
+        S1 o;
+        const int rel = 16 * step + 8 * g + 2 * w;
+        const uint32_t ra = clampr(rel), rb = clampr(rel + 1);
+        o.ea = sdb[ra]; o.eb = sdb[rb];
+        o.da = dzb[ra]; o.db = dzb[rb];
+        o.mw = abb[clampr(16 * step + srow) * WPR + sword];
+        o.dl = dzb[clampr(16 * step + (lane & 15))];
+        return o;
+    };
+    auto load_rows = [&](const S1& i) {
+        S2 o;
+        const uint32_t un = static_cast<uint32_t>(N);
+        o.as = *reinterpret_cast<const float2*>(codes + (static_cast<uint32_t>(i.ea.x) * un + coff));
+        o.ad = *reinterpret_cast<const float2*>(codes + (static_cast<uint32_t>(i.ea.y) * un + coff));
+        o.bs = *reinterpret_cast<const float2*>(codes + (static_cast<uint32_t>(i.eb.x) * un + coff));
+        o.bd = *reinterpret_cast<const float2*>(codes + (static_cast<uint32_t>(i.eb.y) * un + coff));
+        o.da = i.da; o.db = i.db; o.mw = i.mw; o.dl = i.dl;
+        return o;
+    };
+    auto publish = [&](const S2& r, int step, uint32_t* stg) {
+        const int rel = 16 * step + 8 * g + 2 * w;
+        const float da = rel < lim ? r.da : 0.f, db = rel + 1 < lim ? r.db : 0.f;          // rows past the half count for nothing
+        // feat = x_s * x_d rounded once, then the row factor, then the exact three-way split: as the materialised form did
+        const float a0 = (r.as.x * r.ad.x) * da, a1 = (r.as.y * r.ad.y) * da;
+        const float b0 = (r.bs.x * r.bd.x) * db, b1 = (r.bs.y * r.bd.y) * db;
+        uint32_t p1, p2, p3;
+        split3(a0, b0, p1, p2, p3);                          // column n0 + 2 l31     (u = 0): rows (8 g + 2 w, + 1) = dword m = w of its fragments
+        stg[((0 * 3 + 0) * 64 + lane) * 4 + w] = p1; stg[((0 * 3 + 1) * 64 + lane) * 4 + w] = p2; stg[((0 * 3 + 2) * 64 + lane) * 4 + w] = p3;
+        split3(a1, b1, p1, p2, p3);                          // column n0 + 2 l31 + 1 (u = 1)
+        stg[((1 * 3 + 0) * 64 + lane) * 4 + w] = p1; stg[((1 * 3 + 1) * 64 + lane) * 4 + w] = p2; stg[((1 * 3 + 2) * 64 + lane) * 4 + w] = p3;
+        if (stage_mask) stg[kBst + sword * 16 + srow] = r.mw;
+        if (stage_dz) stg[kBst + kMst + lane] = __float_as_uint(16 * step + lane < lim ? r.dl : 0.f);
+        if (want_dz && l31 == 0) dzs += da + db;             // every row of the step exactly once over (w, g)
+    };
+    // hidden units of this wave: h = 32 MT w + MT l31 + t (interleaved: one mask word serves both tiles)
+    const int wsel = MT * w + ((MT * l31) >> 5), wsh = (MT * l31) & 31;
+    // A step's operands: read from LDS and expanded after the barrier, with the MFMAs.  (Measured at K = 100 000: reading them BEFORE the
+    // barrier, behind the next step's publish arithmetic, 88 us; reading and expanding them there, 104 us; all of it after the barrier,
+    // 81 us -- the half-step offset between the K-groups wants about half of a wave's work on either side of the barrier.)
+    struct Ops { bf16x8 bq[2][3]; uint4 m0, m1; uint32_t cw[8 / NG]; float cd[8 / NG]; };
+    auto fetch = [&](const uint32_t* stg, Ops& o) {
+        o.m0 = *reinterpret_cast<const uint4*>(stg + kBst + wsel * 16 + 8 * g);
+        o.m1 = *reinterpret_cast<const uint4*>(stg + kBst + wsel * 16 + 8 * g + 4);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+                o.bq[u][pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(stg + ((u * 3 + pc) * 64 + lane) * 4));
+        if (want_cs) {
+            // this column group's rows of every 8 (rpg of them): their mask word and dz straight from LDS (a runtime row index into
+            // registers would put them in scratch)
+#pragma unroll
+            for (int jj = 0; jj < rpg; ++jj) {
+                const int j = 8 * g + ng * rpg + jj;
+                o.cw[jj] = stg[kBst + wsel * 16 + j];
+                o.cd[jj] = __uint_as_float(stg[kBst + kMst + j]);
+            }
+        }
+    };
+    auto mma = [&](const Ops& o) {
+        uint32_t aw[8] = {o.m0.x, o.m0.y, o.m0.z, o.m0.w, o.m1.x, o.m1.y, o.m1.z, o.m1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) aw[j] >>= wsh;
+        uint32_t c[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) c[m] = (aw[2 * m] & ((1u << MT) - 1u)) | ((aw[2 * m + 1] & ((1u << MT) - 1u)) << 16);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            u32x4 A1;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) A1[m] = __umul24((c[m] >> t) & 0x00010001u, 0x3F80u);         // bf16 1.0 / 0.0 pairs of rows 2 m, 2 m + 1
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, A1);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, o.bq[u][2], acc[t][u], 0, 0, 0);      // smallest terms first
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, o.bq[u][1], acc[t][u], 0, 0, 0);
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, o.bq[u][0], acc[t][u], 0, 0, 0);
+            }
+        }
+        if (want_cs) {
+#pragma unroll
+            for (int jj = 0; jj < rpg; ++jj) {
+                const uint32_t wv = o.cw[jj] >> wsh;
+#pragma unroll
+                for (int t = 0; t < MT; ++t) cs[t] += (wv >> t) & 1u ? o.cd[jj] : 0.f;
+            }
+        }
+    };
+    {
+        // row stages AND endpoint stages ping-pong over a loop unrolled by two (nsteps is even): every loop-carried register has ONE
+        // definition inside the loop, so nothing is copied across the back edge -- a copy of a load's result is a wait for it
+        S1 ia = load_idx(0);
+        S2 ra = load_rows(ia);
+        S1 ib = load_idx(1);
+        S2 rb = load_rows(ib);
+        ia = load_idx(2);
+        publish(ra, 0, st0);
+        int sa = 0, sb = 1;                                  // stage of step i, of step i + 1
+        // The barrier keeps a K-group's waves in step, and a SIMD holds one wave of each group: with one barrier per step both would
+        // multiply at the same time (sharing the matrix pipe) and then both publish (the pipe idle) -- measured 1.5 us per step.  Two
+        // barriers per step, and group 1 runs HALF A STEP behind (one barrier more before its loop, one fewer after): while a SIMD's
+        // group-0 wave multiplies, its group-1 wave loads, splits and publishes, and vice versa.
+        if (kg == 1) __syncthreads();
+        Ops op;
+#pragma unroll 1
+        for (int i = 0; i < nsteps; i += 2) {
+            ra = load_rows(ia);                              // rows of step i + 2
+            ib = load_idx(i + 3);                            // endpoints, dz, mask word of step i + 3
+            publish(rb, i + 1, st0 + sb * kStage);           // step i + 1
+            __syncthreads();
+            fetch(st0 + sa * kStage, op);                    // step i
+            mma(op);
+            __syncthreads();
+            sa = sb; sb = sb == 2 ? 0 : sb + 1;
+            rb = load_rows(ib);                              // rows of step i + 3
+            ia = load_idx(i + 4);
+            publish(ra, i + 2, st0 + sb * kStage);           // step i + 2
+            __syncthreads();
+            fetch(st0 + sa * kStage, op);
+            mma(op);
+            __syncthreads();
+            sa = sb; sb = sb == 2 ? 0 : sb + 1;
+        }
+        if (kg == 0) __syncthreads();
+    }
+    // ---- sum of the two K-groups (fixed order: group 0 + group 1), one tile row at a time through the (now dead) stages
+    if (want_cs) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) cs[t] += __shfl_xor(cs[t], 32, 64);
+    }
+    dzs += __shfl_xor(dzs, 32, 64);
+    float* red = reinterpret_cast<float*>(lds);
+    constexpr int kRedCs = 4 * 2 * 16 * 64, kRedDz = kRedCs + 4 * MT * 64;
+    static_assert(kRedDz + 8 <= 2 * 3 * kStage, "the K-group sum reuses the stages");
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        __syncthreads();                                     // t = 0: every wave is through its last multiply; t = 1: group 0 has read tile row 0
+        if (t == 0 && lane == 0) red[kRedDz + wave] = dzs;
+        if (kg == 1) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((w * 2 + u) * 16 + r) * 64 + lane] = acc[t][u][r];
+            if (t == 0) {
+#pragma unroll
+                for (int tt = 0; tt < MT; ++tt) red[kRedCs + (w * MT + tt) * 64 + lane] = cs[tt];
+            }
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][u][r] += red[((w * 2 + u) * 16 + r) * 64 + lane];
+            if (t == 0) {
+#pragma unroll
+                for (int tt = 0; tt < MT; ++tt) cs[tt] += red[kRedCs + (w * MT + tt) * 64 + lane];
+                if (want_dz && wave == 0 && lane == 0) {
+                    float a = 0.f;
+                    for (int z = 0; z < 8; ++z) a += red[kRedDz + z];
+                    dzpart[slab_id] = a;
+                }
+            }
+        }
+    }
+    if (kg != 0) return;
+    float* out = slab + static_cast<int64_t>(slab_id) * M * N;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int h = 32 * MT * w + MT * ((r & 3) + 8 * (r >> 2) + 4 * g) + t;
+            *reinterpret_cast<float2*>(out + static_cast<int64_t>(h) * N + n0 + 2 * l31) = make_float2(acc[t][0][r], acc[t][1][r]);
+        }
+    if (want_cs && g == 0) {
+        float* cp = cpart + (static_cast<int64_t>(slab_id) * NG + ng) * M + 32 * MT * w + MT * l31;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) cp[t] = cs[t];
+    }
+}
+
+constexpr int kMaskfeatMaxSlabs = 128;
 inline bool use_tall(int64_t K, int64_t M, int64_t N) { return K >= kTallK && M % 4 == 0 && N % 2 == 0; }
 inline int pick_ksplit_tall(int64_t K, int64_t M, int64_t N) {
     const int64_t tiles = cdiv(M, 128) * cdiv(N, 64);
@@ -567,7 +830,8 @@ extern "C" {
 size_t sgs_gemm_tn_workspace_bytes(int64_t K, int64_t M, int64_t N) {
     if (K < 0 || M < 0 || N < 0) return 256;
     const size_t ks = static_cast<size_t>(pick_ksplit(K, M, N));
-    return carve_bytes(ks * M * N, 4) + carve_bytes(ks * M, 4) + 256;       // split-K slabs + column-sum partials
+    return carve_bytes(ks * M * N, 4) + carve_bytes(ks * M, 4) + carve_bytes(kMaskfeatMaxSlabs * 8 * M + kMaskfeatMaxSlabs, 4) + 512;
+    // split-K slabs + column-sum partials (+ the shared-operand kernel's: up to 8 column groups per slab, and its dz sums)
 }
 
 static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, float* colsum_A, void* ws,
@@ -577,6 +841,9 @@ static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, in
 // tall-K shapes: 1 = bf16x6 kernel (default; measured 147 vs 175 us incl. the 34 us slab reduction at K = 100 000, M = N = 256: the
 // operand splits, 264 vector instructions per 48 MFMAs, are at the budget the matrix pipe leaves), 0 = fp32-MFMA kernel
 static int g_tall_bf16x6 = 1;
+// sgs_gemm_tn_mask_gather: 1 = the shared-operand kernel (gemm_tn_maskfeat, default), 0 = the per-wave-slice kernel; slabs: 0 = automatic
+static int g_gather_shared = 1, g_gather_slabs = 0;
+void sgs_gemm_tn_set_gather_variant(int shared, int slabs) { g_gather_shared = shared ? 1 : 0; g_gather_slabs = slabs > 0 ? slabs : 0; }
 void sgs_gemm_tn_set_tall_variant(int v) { g_tall_bf16x6 = v < 0 ? 1 : (v ? 1 : 0); }
 
 int sgs_gemm_tn(const float* A, const float* B, int64_t K, int64_t M, int64_t N, float* C, void* ws, size_t ws_bytes,
@@ -660,6 +927,33 @@ static int gemm_tn_impl(const float* A, const float* B, int64_t K, int64_t M, in
         n_slabs = ks / NW;
         // cpart holds ks * M floats and the NW-wave workgroups fill n_slabs * M of them: the K-slices' dz sums go behind those
         float* dzpart = dz_sum ? cpart + static_cast<size_t>(n_slabs) * M : nullptr;
+        const int NGc = static_cast<int>(N / 64);
+        if (sd && g_gather_shared && (M == 128 || M == 256) && N % 64 == 0 && (NGc == 1 || NGc == 2 || NGc == 4 || NGc == 8) && K >= 64) {
+            // shared-operand kernel: one slab per 8-wave workgroup, NGc column-sum rows per slab
+            int ns = g_gather_slabs > 0 ? g_gather_slabs : 256 / NGc;                   // one workgroup (two waves per SIMD) per CU
+            while (ns > 1 && K / ns < 64) ns >>= 1;                                      // >= two steps per K-group
+            if (ns > kMaskfeatMaxSlabs) ns = kMaskfeatMaxSlabs;
+            if (ns > ks) ns = ks;                                                        // the slab carving is sized for ks slices
+            float* cpart2 = cv.take<float>(static_cast<size_t>(kMaskfeatMaxSlabs) * 8 * M + kMaskfeatMaxSlabs);
+            float* dzp = dz_sum ? cpart2 + static_cast<size_t>(ns) * NGc * M : nullptr;
+            const size_t lds_b = static_cast<size_t>(2 * 3 * (2 * 3 * 64 * 4 + (M / 32) * 16 + 16)) * 4;
+            const dim3 grid(static_cast<unsigned>(NGc), static_cast<unsigned>(ns));
+            float* cpa = (colsum_A || dz_sum) ? cpart2 : static_cast<float*>(nullptr);
+            const int2* sd2 = reinterpret_cast<const int2*>(sd);
+            const int Ni = static_cast<int>(N);
+#define SGS_MASKFEAT(MT_, NG_) hipLaunchKernelGGL((gemm_tn_maskfeat<MT_, NG_>), grid, dim3(512), lds_b, stream, Abits, dz, B, sd2, K, Ni, slab, cpa, dzp)
+            if (M == 256) {
+                if (NGc == 1) SGS_MASKFEAT(2, 1); else if (NGc == 2) SGS_MASKFEAT(2, 2); else if (NGc == 4) SGS_MASKFEAT(2, 4); else SGS_MASKFEAT(2, 8);
+            } else {
+                if (NGc == 1) SGS_MASKFEAT(1, 1); else if (NGc == 2) SGS_MASKFEAT(1, 2); else if (NGc == 4) SGS_MASKFEAT(1, 4); else SGS_MASKFEAT(1, 8);
+            }
+#undef SGS_MASKFEAT
+            hipLaunchKernelGGL(gemm_tn_reduce, dim3(cdiv(M * N + M + 1, 256)), dim3(256), 0, stream, slab, M * N, ns, C,
+                               static_cast<const float*>(colsum_A ? cpart2 : nullptr), static_cast<int>(M), colsum_A, static_cast<int>(N),
+                               ldc > 0 ? ldc : N, rowscale, scale, static_cast<const float*>(dzp), ns, dz_sum, C_raw, colsum_raw, ns * NGc);
+            SGS_LAUNCH_OK();
+            return SGS_OK;
+        }
         if (sd) {
             static bool raised_g = false;
             if (!raised_g) {

@@ -422,9 +422,10 @@ def test_fused_backward_equals_unfused_backward(ops, N, H, p, q):
             assert bool(torch.isfinite(a).all()), (form, name)
             # (d b2 is ONE sum of q signed terms: its relative error is the summation order's, not the kernels')
             assert _rel(a, b) < (2e-5 if name == "db2" else 3e-6), (form, name, _rel(a, b))
-    # the weight gradient gathers exactly the products the materialised feat held, in the same order: bit-identical
-    assert torch.equal(grads["fused"][1][:, :H], grads["unfused"][1][:, :H])
-    assert torch.equal(grads["fused"][2], grads["unfused"][2]) and torch.equal(grads["fused"][4], grads["unfused"][4])
+    # the weight gradient gathers exactly the products the materialised feat held; the shared-operand kernel (round 3) sums them in
+    # another order than the per-wave-slice kernel of the unfused form
+    assert _rel(grads["fused"][1][:, :H], grads["unfused"][1][:, :H]) < 2e-6
+    assert _rel(grads["fused"][2], grads["unfused"][2]) < 2e-6 and _rel(grads["fused"][4], grads["unfused"][4]) < 2e-5
 
 
 @pytest.mark.parametrize("H,p,n", [(256, 0.3, 66_003), (128, 0.0, 70_000), (256, 0.0, 95)])
@@ -546,3 +547,54 @@ def test_paired_forward_is_run_to_run_deterministic_at_arxiv_size(ops):
             for it in range(25):
                 p1 = ops.edge_score(cd, W1, b1, W2, b2, b.edge_index, pairs=pairs, p=0.3, seed=3, site=2).detach()
                 assert torch.equal(p1, p0), (grad, it, int((p1 != p0).sum()))
+
+
+@pytest.mark.parametrize("K,H,N", [(100_000, 256, 1013), (70_001, 128, 500), (8_200, 256, 64), (131_072, 256, 33_869)])
+def test_gather_weight_gradient_shared_operand_kernel(K, H, N):
+    """sgs_gemm_tn_mask_gather, shared-operand kernel (the four waves of a K-group split a step's rows once and exchange fragments through
+    LDS) against fp64 and against the per-wave-slice kernel of round 2: C (strided), C_raw, column sums (raw and scaled), dz sum.
+    Ragged K (not a multiple of the step), both hidden widths, a table larger than L2."""
+    import sgs_gnn_amd as S
+    ops, L = S.ops, S._lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(K + H)
+    codes = torch.relu(torch.randn(N, H, device=DEV, generator=g))
+    sd = torch.randint(0, N, (K, 2), device=DEV, generator=g, dtype=torch.int32)
+    bits = torch.randint(-2**31, 2**31 - 1, (K, H // 32), device=DEV, generator=g, dtype=torch.int64).to(torch.int32)
+    dz = torch.randn(K, device=DEV, generator=g)
+    w2 = torch.randn(H, device=DEV, generator=g)
+    scale = 1.0 / 0.7
+    assert L.sgs_gemm_tn_mask_supported(K, H, H)
+    ws = ops.workspace(L.sgs_gemm_tn_workspace_bytes(K, H, H), codes.device)
+
+    def run(shared, slabs=0):
+        L.sgs_gemm_tn_set_gather_variant(shared, slabs)
+        C = torch.full((H, 2 * H), 7.0, device=DEV)
+        cs, dzs, Craw, csraw = torch.empty(H, device=DEV), torch.empty(1, device=DEV), torch.empty(H, H, device=DEV), torch.empty(H, device=DEV)
+        S._lib.check(L.sgs_gemm_tn_mask_gather(bits.data_ptr(), dz.data_ptr(), w2.data_ptr(), scale, codes.data_ptr(), N, sd.data_ptr(), K, H, H,
+                                               C.data_ptr(), 2 * H, cs.data_ptr(), dzs.data_ptr(), Craw.data_ptr(), csraw.data_ptr(), ws.data_ptr(),
+                                               ws.numel(), ops._stream()), "gather")
+        torch.cuda.synchronize()
+        return C, cs, dzs, Craw, csraw
+
+    try:
+        new = run(1)
+        new2 = run(1)
+        odd = run(1, 37)                      # a slab count that leaves ragged halves and an empty trailing one
+        old = run(0)
+    finally:
+        L.sgs_gemm_tn_set_gather_variant(1, 0)
+    for a, b in zip(new, new2):
+        assert torch.equal(a, b)              # run-to-run deterministic
+    bw = torch.arange(32, device=DEV, dtype=torch.int32)
+    mask = ((bits.unsqueeze(2) >> bw) & 1).reshape(K, H).double()
+    feat = (codes[sd[:, 0].long()] * codes[sd[:, 1].long()]).double()
+    dv = mask * dz.double().unsqueeze(1)
+    Traw = dv.t() @ feat
+    csr = dv.sum(0)
+    want = (Traw * (w2.double() * scale).unsqueeze(1), csr * w2.double() * scale, dz.double().sum().reshape(1), Traw, csr)
+    for got in (new, odd, old):
+        assert torch.all(got[0][:, H:] == 7.0)                       # the strided result leaves the other half of the rows alone
+        for name, a, b in zip(("C", "colsum", "dzsum", "Craw", "colsum_raw"), (got[0][:, :H], got[1], got[2], got[3], got[4]), want):
+            err = float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+            assert err < 2e-6, (name, err)
+
