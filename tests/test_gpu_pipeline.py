@@ -134,8 +134,8 @@ def test_train_replays_reference_fixture_at_partition_size():
 
 def test_hybrid_mlp_scorer_with_dropout_matches_oracle():
     """hybrid + --edge_mlp_type MLP + conditional False + dropout > 0 (the reference's only working training configuration of
-    EdgeProbMLP): the per-(edge, endpoint) dropout of model.py:21-25 keeps the scorer on its endpoint-table
-    path, whose backward must run over that table's own pseudo-graph.  Inputs / initial state: the reference fixture
+    EdgeProbMLP): the per-(edge, endpoint) dropout of model.py:21-25 runs inside the scorer kernel
+    (sgs_edge_score_epd_*: hash keyed on (site, edge, endpoint); no endpoint table).  Inputs / initial state: the reference fixture
     pipeline_hybrid_mlp_drop.pt (which pins the oracle's EdgeProbMLP-with-dropout in tests/test_oracle_golden.py); the dropout
     masks are the product's counter-based ones, exported to the oracle."""
     import sgs_gnn_amd as S
