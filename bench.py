@@ -600,6 +600,8 @@ def run_s5(a, S, rank, world, device, steps=None, warmup=None):
         S.fix_seeds(1)
         return build_model(S, device, fused=True)
 
+    warm_ei = [None]
+
     def timed_steps(one_step):
         for _ in range(warmup):
             one_step()
@@ -607,8 +609,10 @@ def run_s5(a, S, rank, world, device, steps=None, warmup=None):
         # pays one-time costs inside the timed region (growing the scratch arena by the sort workspace of the drawn subgraph, loading the
         # radix-sort code objects, the cached source-sortedness check of the edge list: ~1 s once, measured).  One draw + subgraph build here.
         with torch.no_grad():
-            smp = S.ops.sample_topq(S.ops.SAMPLE_LEARNED, torch.rand(E, device=device), None, 0.0, q, b.edge_index, seed=11, stream_id=3)
-            S.ops.get_subgraph(b.edge_index, N, smp)
+            ei_w = b.edge_index if b.edge_index is not None else warm_ei[0]          # (sharded: this rank's slice)
+            ew = ei_w.shape[1]
+            smp = S.ops.sample_topq(S.ops.SAMPLE_LEARNED, torch.rand(ew, device=device), None, 0.0, max(min(q, ew - 1), 1), ei_w, seed=11, stream_id=3)
+            S.ops.get_subgraph(ei_w, N, smp)
             del smp
         torch.cuda.synchronize()
         torch.cuda.synchronize()
@@ -639,6 +643,7 @@ def run_s5(a, S, rank, world, device, steps=None, warmup=None):
     else:
         shard = sh.EdgeShard(b, rank, world)
         b.edge_index = b.prob = None                 # the shard holds this rank's slice; node data stay replicated
+        warm_ei[0] = shard.edge_index
         torch.cuda.empty_cache()
         for name, fn in (("allreduce", sh.train_step_sharded), ("nodeblock", sh.train_step_blocksharded)):
             model, og, oe, oa = fresh()
