@@ -145,6 +145,20 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce(const float* __restrict__ 
         return;
     }
     float acc = 0.f;
+    if (csplit > 0) {
+        // the shared-operand kernel's slabs: eight loads in flight, eight running sums joined in a fixed tree
+        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 8 <= ksplit; s += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = slab[static_cast<int64_t>(s + j) * mn + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a8[j] += v[j];
+        }
+        for (; s < ksplit; ++s) a8[0] += slab[static_cast<int64_t>(s) * mn + i];
+        acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    } else
     for (int s = 0; s < ksplit; ++s) acc += slab[static_cast<int64_t>(s) * mn + i];
     if (Craw) Craw[i] = acc;                             // dense [M, N], before the row factor
     if (rowscale) acc *= rowscale[i / N] * scale;        // mask-operand products: row m of C carries the factor left out of A

@@ -392,11 +392,14 @@ __device__ __forceinline__ bool dyn_range(const int64_t* __restrict__ dynE, int6
 template <int MODE>   // 1: max, otherwise sum (fixed tree, as reduce_final); result in every thread
 __device__ __forceinline__ float final_reduce_all(const float* __restrict__ part, int64_t n, float* red) {
     float acc = (MODE == 1) ? -INFINITY : 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += kThreads) {
-        const float v = part[i];
-        if (MODE == 1) acc = fmaxf(acc, v);
-        else acc += v;
-    }
+    // (the first kThreads threads only: a wider workgroup -- small_keys_hist0 -- reduces in exactly the order of a kThreads-wide one; the
+    //  other waves contribute the identity to the fixed tree)
+    if (threadIdx.x < kThreads)
+        for (int64_t i = threadIdx.x; i < n; i += kThreads) {
+            const float v = part[i];
+            if (MODE == 1) acc = fmaxf(acc, v);
+            else acc += v;
+        }
     if (MODE == 1) return block_max(acc, red);
     const float r = block_sum(acc, red);
     __shared__ float bc;
@@ -504,42 +507,47 @@ __global__ void __launch_bounds__(kThreads) small_reduce_sumexp(const float* __r
     if (threadIdx.x == 0) part_sum[blockIdx.x] = r;
 }
 
-constexpr int kKeyItems = 8;          // edges per thread in the key pass.  (2, i.e. 512-edge workgroups, was tried to spread a partition over
-                                      // more CUs: 31 us instead of 19 -- the per-workgroup redundant reductions and the 2048-bin flush dominate)
+// The key pass: 2 048 edges per workgroup as everywhere (one histogram flush and one redundant reduction per 2 048 keys), but 1 024 threads
+// with TWO edges each.  With 256 threads x 8 edges (rounds 1-2) a partition's 172-242 workgroups put one wave on a SIMD, each running eight
+// Philox draws back to back behind the reductions' round trips: 19 us under the counters, 65 % of it waiting (r03 PMC).  Sixteen waves per
+// workgroup overlap those latencies.  (512-edge workgroups were tried in round 2: slower, four times the flushes and reductions.)
+constexpr int kKeyThreads = 1024;
+constexpr int kKeyItems = kChunk / kKeyThreads;
 template <int MODE>
-__global__ void __launch_bounds__(kThreads) small_keys_hist0(const float* __restrict__ p, const float* __restrict__ prior,
-                                                            const float* __restrict__ noise, uint64_t seed, uint64_t stream_id,
-                                                            const uint64_t* __restrict__ epoch, int64_t E, float one_minus_c, float c,
-                                                            const float* __restrict__ part_sum, const float* __restrict__ part_max,
-                                                            int64_t nblk, float* __restrict__ scal, uint32_t* __restrict__ keys,
-                                                            float* __restrict__ keys_out, uint32_t* __restrict__ hist0,
-                                                            const int64_t* __restrict__ dynE) {
+__global__ void __launch_bounds__(kKeyThreads) small_keys_hist0(const float* __restrict__ p, const float* __restrict__ prior,
+                                                               const float* __restrict__ noise, uint64_t seed, uint64_t stream_id,
+                                                               const uint64_t* __restrict__ epoch, int64_t E, float one_minus_c, float c,
+                                                               const float* __restrict__ part_sum, const float* __restrict__ part_max,
+                                                               int64_t nblk, float* __restrict__ scal, uint32_t* __restrict__ keys,
+                                                               float* __restrict__ keys_out, uint32_t* __restrict__ hist0,
+                                                               const int64_t* __restrict__ dynE) {
     __shared__ uint32_t lh[kBins];
-    __shared__ float red[kThreads / 64];
+    __shared__ float red[kKeyThreads / 64];
     if (!dyn_range(dynE, E, nblk)) return;
-    for (int i = threadIdx.x; i < kBins; i += kThreads) lh[i] = 0;
+    for (int i = threadIdx.x; i < kBins; i += kKeyThreads) lh[i] = 0;
     seed = fold_epoch(seed, epoch);
-    const float mx = (MODE == SGS_SAMPLE_PRIOR) ? final_reduce_all<1>(part_max, nblk, red) : 0.f;
-    const float Z = final_reduce_all<0>(part_sum, nblk, red);          // (syncs: lh is cleared for everyone)
-    if (blockIdx.x == 0 && threadIdx.x == 0) { scal[0] = Z; scal[1] = mx; }
-    const float Zeps = (MODE == SGS_SAMPLE_LEARNED) ? __fadd_rn(Z, 1e-12f) : Z;
     const bool has_prior = prior != nullptr;
-    const int64_t base = static_cast<int64_t>(blockIdx.x) * (kThreads * kKeyItems);
-    float pv[kKeyItems], qv[kKeyItems], nv[kKeyItems];      // every load of the thread in flight before the first use (see small_reduce_first)
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * kChunk;
+    // every load of the thread in flight before the reductions' barriers and before the first use
+    float pv[kKeyItems], qv[kKeyItems], nv[kKeyItems];
 #pragma unroll
     for (int i = 0; i < kKeyItems; ++i) {
-        const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
+        const int64_t e = base + static_cast<int64_t>(i) * kKeyThreads + threadIdx.x;
         const int64_t ec = e < E ? e : E - 1;
         pv[i] = p ? p[ec] : 1.f;
         qv[i] = has_prior ? prior[ec] : 0.f;
         nv[i] = noise ? noise[ec] : 0.f;
     }
-    // all eight keys in registers BEFORE the first store: vmcnt counts stores too on this target, and behind the per-item branches the
-    // compiler's wait for an item's (long finished) loads was vmcnt(0) -- i.e. for the previous item's key store, eight times over
+    const float mx = (MODE == SGS_SAMPLE_PRIOR) ? final_reduce_all<1>(part_max, nblk, red) : 0.f;
+    const float Z = final_reduce_all<0>(part_sum, nblk, red);          // (syncs: lh is cleared for everyone)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { scal[0] = Z; scal[1] = mx; }
+    const float Zeps = (MODE == SGS_SAMPLE_LEARNED) ? __fadd_rn(Z, 1e-12f) : Z;
+    // all keys in registers BEFORE the first store: vmcnt counts stores too on this target, and behind per-item branches the compiler's
+    // wait for an item's (long finished) loads was vmcnt(0) -- i.e. for the previous item's key store
     float kf[kKeyItems];
 #pragma unroll
     for (int i = 0; i < kKeyItems; ++i) {
-        const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
+        const int64_t e = base + static_cast<int64_t>(i) * kKeyThreads + threadIdx.x;
         kf[i] = 0.f;
         if (e < E) {
             const float s = sample_prob<MODE>(pv[i], Zeps, mx, qv[i], has_prior, one_minus_c, c);
@@ -549,7 +557,7 @@ __global__ void __launch_bounds__(kThreads) small_keys_hist0(const float* __rest
     }
 #pragma unroll
     for (int i = 0; i < kKeyItems; ++i) {
-        const int64_t e = base + static_cast<int64_t>(i) * kThreads + threadIdx.x;
+        const int64_t e = base + static_cast<int64_t>(i) * kKeyThreads + threadIdx.x;
         if (e < E) {
             const uint32_t bits = __float_as_uint(kf[i]);
             keys[e] = bits;
@@ -558,7 +566,7 @@ __global__ void __launch_bounds__(kThreads) small_keys_hist0(const float* __rest
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kBins; i += kThreads) {
+    for (int i = threadIdx.x; i < kBins; i += kKeyThreads) {
         const uint32_t v = lh[i];
         if (v) atomicAdd(&hist0[i], v);
     }
@@ -901,15 +909,15 @@ int sgs_sample_topq(int mode, const float* p, const float* prior, double degree_
         // fused small-E path: 6 / 7 launches (see "fused small-E path" above); same arithmetic, same results
         const uint32_t q32 = static_cast<uint32_t>(q);
         uint32_t *h0 = hist3, *h1 = hist3 + kBins, *h2 = hist3 + 2 * kBins;
-        const dim3 kgrid(static_cast<unsigned>(cdiv(E, kThreads * kKeyItems)));
+        const dim3 kgrid(static_cast<unsigned>(nblk)), kblk(kKeyThreads);
         if (mode == SGS_SAMPLE_LEARNED) {
             hipLaunchKernelGGL(small_reduce_first<0>, grid, blk, 0, stream, p, E, part, hist3, dynE);
-            hipLaunchKernelGGL(small_keys_hist0<SGS_SAMPLE_LEARNED>, kgrid, blk, 0, stream, p, prior, noise, seed, stream_id, epoch_ptr(), E,
+            hipLaunchKernelGGL(small_keys_hist0<SGS_SAMPLE_LEARNED>, kgrid, kblk, 0, stream, p, prior, noise, seed, stream_id, epoch_ptr(), E,
                                one_minus_c, c, part, static_cast<const float*>(nullptr), nblk, scal, keys, keys_out, h0, dynE);
         } else {
             hipLaunchKernelGGL(small_reduce_first<1>, grid, blk, 0, stream, p, E, part, hist3, dynE);
             hipLaunchKernelGGL(small_reduce_sumexp, grid, blk, 0, stream, p, E, part, nblk, part2, dynE);
-            hipLaunchKernelGGL(small_keys_hist0<SGS_SAMPLE_PRIOR>, kgrid, blk, 0, stream, p, static_cast<const float*>(nullptr), noise, seed,
+            hipLaunchKernelGGL(small_keys_hist0<SGS_SAMPLE_PRIOR>, kgrid, kblk, 0, stream, p, static_cast<const float*>(nullptr), noise, seed,
                                stream_id, epoch_ptr(), E, one_minus_c, c, part2, part, nblk, scal, keys, keys_out, h0, dynE);
         }
         hipLaunchKernelGGL(small_hist_next, grid, blk, 0, stream, keys, E, kShift1, kMask1, kShift0, 1, q32, h0,
