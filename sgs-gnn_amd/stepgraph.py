@@ -777,6 +777,7 @@ class StepGraphs:
 
 class _ReplayHandle:
     __slots__ = ("sg", "c", "sampled", "cbuf", "opt_in_graph", "seq0", "loss_on_device", "dp_in_handle")
+    replayed = True                                    # training.py: no zero_grad() needed, backward() attaches the captured gradient buffers
 
     def __init__(self, sg, c, seq0):
         self.sg, self.c, self.sampled, self.cbuf = sg, c, c.sampled, c.cbuf
@@ -824,6 +825,7 @@ class _EagerHandle:
     collectives -- a different sequence (a flag all-reduce, GradSync.sync) would pair up with the wrong calls on the other ranks --
     so its backward writes the gradients and the flag into the bucket, all-reduces it and replays g3 as well."""
     __slots__ = ("sg", "batch", "sampled", "cbuf", "st", "opt_in_graph", "loss_on_device", "dp_in_handle")
+    replayed = False
 
     def __init__(self, sg, batch):
         from .training import sampled_forward

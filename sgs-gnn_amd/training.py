@@ -299,6 +299,9 @@ def _null_step(args, mode, model, optimizer_gnn, optimizer_edge_prob, optimizer,
     optimizer_gnn.step()
 
 
+_ALWAYS_ZERO_GRAD = False       # A/B switch (tools/host_ab.py): zero both optimisers at the top of every step, replayed or not
+
+
 def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimizer_edge_prob, optimizer, criterion,
                 cluster_loader, q, device, mode, use_checkpoint, noise, trace, sync, graphs):
     total_loss = None
@@ -320,8 +323,13 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
             continue
         ops.new_memo_scope()                    # per-step memos (x W^T shared by the learned and the random forward) die here
         total_update += 1
-        optimizer_edge_prob.zero_grad()
-        optimizer_gnn.zero_grad()
+        # training_hybrid.py:52-53 zeroes both optimisers' gradients at the top of every step.  A REPLAYED step neither accumulates into
+        # .grad nor reads it: its captured backward writes static buffers, which h.backward() then attaches to every parameter (None for
+        # the ones without a gradient) -- and two torch zero_grad() calls are ~50 us of host time, more than the host has to spare beside
+        # an unsampled step's 140 us of GPU work.  So in graph mode the zeroing happens only for steps that run eagerly.
+        if graphs is None or mode != 'learned' or _ALWAYS_ZERO_GRAD:
+            optimizer_edge_prob.zero_grad()
+            optimizer_gnn.zero_grad()
 
         if mode == 'learned':
             batch = batch.to(device)
@@ -330,6 +338,9 @@ def _epoch_loop(pipeline, args, epoch, max_epoch, model, optimizer_gnn, optimize
             if graphs is not None:
                 nxt = batch_after.to(device) if batch_after is not None and _has_train_nodes(batch_after) else None
                 h = graphs.forward(batch, nxt)
+                if not getattr(h, "replayed", False) and not _ALWAYS_ZERO_GRAD:
+                    optimizer_edge_prob.zero_grad()
+                    optimizer_gnn.zero_grad()
             else:
                 h = None
             eager_opt = h is None or not h.opt_in_graph       # capturable optimisers are stepped inside the backward graph

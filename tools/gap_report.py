@@ -5,7 +5,7 @@
 
 Kernels of ALL streams are merged into one busy/idle timeline (a gap = no kernel running on any stream).  The window is the last
 `steps` (default 460 = two 230-partition epochs) training steps: from the start of the staging kernel of the first of them to the end of
-the last loss_tick."""
+the last loss_tick (round 3: the last adam_multi launch, which carries the tick)."""
 import csv
 import glob
 import sys
@@ -20,7 +20,7 @@ for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 stage = [r[0] for r in rows if "stage_segments_kernel" in r[2]]
-ticks = [r[1] for r in rows if "loss_tick" in r[2]]
+ticks = [r[1] for r in rows if "loss_tick" in r[2]] or [r[1] for r in rows if "adam_multi" in r[2]]      # (round 3: the tick rides in adam_multi)
 lo, hi = stage[-steps], ticks[-1]
 rows = [r for r in rows if r[0] >= lo and r[1] <= hi]
 busy_end, prev = rows[0][0], None
