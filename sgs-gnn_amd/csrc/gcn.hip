@@ -312,13 +312,18 @@ __global__ void __launch_bounds__(kT) filter_count_scatter(const int* __restrict
     if (lane == 0) (out ? cnt_out : cnt_in)[row] = c;
 }
 
-template <bool BITS>
+// SCAN: the child row pointers are not there yet -- every wave sums the counts of the rows before its own (N <= kSelfScanRows: a few
+// cached loads per lane) and writes its entry of the pointer array (the last row also the total): the scan launch between the count and
+// the fill pass goes away (partition scale: one launch = ~5 us of a ~90 us draw-to-normalisation chain).
+constexpr int64_t kSelfScanRows = 4096;
+template <bool BITS, bool SCAN = false>
 __global__ void __launch_bounds__(kT) filter_fill(const int* __restrict__ pin_ptr, const int* __restrict__ pin_src, const int* __restrict__ pin_eid,
                                                  const int* __restrict__ pout_ptr, const int* __restrict__ pout_dst,
                                                  const int* __restrict__ pout_eid, int64_t N, const uint8_t* __restrict__ mask,
-                                                 const int* __restrict__ pos, const int* __restrict__ in_ptr, int* __restrict__ in_src,
-                                                 int* __restrict__ in_eid, const int* __restrict__ out_ptr, int* __restrict__ out_dst,
-                                                 int* __restrict__ out_eid, int* __restrict__ loop_eid) {
+                                                 const int* __restrict__ pos, int* __restrict__ in_ptr, int* __restrict__ in_src,
+                                                 int* __restrict__ in_eid, int* __restrict__ out_ptr, int* __restrict__ out_dst,
+                                                 int* __restrict__ out_eid, int* __restrict__ loop_eid, const int* __restrict__ cnt_in = nullptr,
+                                                 const int* __restrict__ cnt_out = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (static_cast<int64_t>(blockIdx.x) * kT + threadIdx.x) >> 6;
     if (r >= 2 * N) return;
@@ -329,7 +334,20 @@ __global__ void __launch_bounds__(kT) filter_fill(const int* __restrict__ pin_pt
     const int* peid = out ? pout_eid : pin_eid;
     int* ccol = out ? out_dst : in_src;
     int* ceid = out ? out_eid : in_eid;
-    int w = (out ? out_ptr : in_ptr)[row];            // write cursor of the child row
+    int w;                                            // write cursor of the child row
+    if constexpr (SCAN) {
+        const int* cnt = out ? cnt_out : cnt_in;
+        int acc = 0;
+        for (int64_t i = lane; i < row; i += 64) acc += cnt[i];
+        w = wave_sum_int_all(acc);
+        if (lane == 0) {
+            int* cptr = out ? out_ptr : in_ptr;
+            cptr[row] = w;
+            if (row == N - 1) cptr[N] = w + cnt[row];
+        }
+    } else {
+        w = (out ? out_ptr : in_ptr)[row];
+    }
     int loop = -1;
     const int b = pptr[row], e = pptr[row + 1];
     // the next 64 entries' (edge id, column) are loaded while this step's mask / position lookups are in flight, and the id / column / mask
@@ -1109,6 +1127,12 @@ int sgs_graph_filter(const int32_t* pin_ptr, const int32_t* pin_src, const int32
         hipLaunchKernelGGL(scan_counts, dim3(2), dim3(1024), 0, stream, cnt_in, cnt_out, N, in_ptr, out_ptr, cur_in, cur_out);
         hipLaunchKernelGGL(filter_fill<true>, g3, blk, 0, stream, pin_ptr, pin_src, pin_eid, pout_ptr, pout_dst, pout_eid, N, bm, pos, in_ptr, in_src,
                            in_eid, out_ptr, out_dst, out_eid, loop_eid);
+    } else if (N <= kSelfScanRows) {
+        hipLaunchKernelGGL(filter_count_scatter<false>, g1, blk, 0, stream, pin_ptr, pin_eid, pout_ptr, pout_eid, N, mask, sampled_eid, q,
+                           n_row_blocks, cnt_in, cnt_out, pos);
+        hipLaunchKernelGGL((filter_fill<false, true>), g3, blk, 0, stream, pin_ptr, pin_src, pin_eid, pout_ptr, pout_dst, pout_eid, N, mask, pos,
+                           in_ptr, in_src, in_eid, out_ptr, out_dst, out_eid, loop_eid, static_cast<const int*>(cnt_in),
+                           static_cast<const int*>(cnt_out));
     } else {
         hipLaunchKernelGGL(filter_count_scatter<false>, g1, blk, 0, stream, pin_ptr, pin_eid, pout_ptr, pout_eid, N, mask, sampled_eid, q,
                            n_row_blocks, cnt_in, cnt_out, pos);
