@@ -354,8 +354,11 @@ def test_backward_core_stream64_matches_lds_tiled(ops, H, p, other):
     assert torch.isfinite(dv1).all() and torch.isfinite(f1).all() and torch.isfinite(dz1).all() and torch.isfinite(h1).all()
     assert torch.equal(f0, f1)                                           # x_s * x_d: the same single product either way
     torch.testing.assert_close(dz1, dz0, rtol=2e-4, atol=1e-6)
-    torch.testing.assert_close(dv1, dv0, rtol=2e-4, atol=1e-6)
-    torch.testing.assert_close(h1, h0, rtol=2e-4, atol=2e-4)
+    # dv = dz w2 relu'(v) keep: the two cores sum v in different orders, so a hidden unit whose pre-activation is within rounding of 0 may
+    # be on in one and off in the other (one entry in 10 M with this seed's masks): a handful of such flips is not an error, more would be
+    bad = (dv1 - dv0).abs() > (1e-6 + 2e-4 * dv0.abs())
+    assert int(bad.sum()) <= 8, int(bad.sum())
+    torch.testing.assert_close(h1, h0, rtol=2e-4, atol=2e-3)
 
 
 @pytest.mark.parametrize("H,n", [(256, 100003), (128, 70000), (256, 65)])
@@ -519,6 +522,11 @@ def test_endpoint_dropout_scorer_vs_fp64_oracle(ops, N, H, E, q, p):
         act.set(eid.to(DEV), ops.Graph(ei[:, eid].to(DEV), N))
     else:
         gp = torch.randn(E, generator=g)
+    # an edge with a hidden unit whose pre-activation is within fp32 rounding of 0 may have that unit on in fp32 and off in fp64 (one such
+    # unit -- |v| = 6e-8 -- among 576 000 with one of the seeds): ReLU' is not continuous there, so those edges carry no gradient here
+    with torch.no_grad():
+        vpre = torch.cat([xm * ym, xm - ym], 1) @ Po[0].t() + Po[1]
+        gp[(vpre.abs() < 1e-5).any(1)] = 0.0
     po.backward(gp.double())
     pd.backward(gp.to(DEV))
     for name, a, b in zip(["dA", "dW1", "db1", "dW2", "db2"], [t.grad for t in dl], [Ao.grad, Po[0].grad, Po[1].grad, Po[2].grad, Po[3].grad]):
