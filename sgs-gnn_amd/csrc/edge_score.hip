@@ -1200,16 +1200,31 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
                         const int j = 3 - jj;
                         const float tb = acc[t][4 * g4 + j] + b4[j];
                         const float v = tb + d4[j];
-                        bool on = v > 0.f;
-                        if constexpr (DROP) on = on & (((j & 1) ? (bits[j >> 1] >> 16) : (bits[j >> 1] & 0xFFFFu)) >= thr);
+                        // the mask word of the wave is the AND of the two compares' own lane masks (a ballot of a COMPARE is the compare's
+                        // SGPR result; a ballot of their conjunction was rebuilt from a 0 / 1 select and one more compare: two more vector
+                        // instructions per unit and direction)
+                        const bool pos = v > 0.f;
+                        bool on = pos;
+                        uint64_t onm = BITS ? __builtin_amdgcn_ballot_w64(pos) : 0ull;
+                        if constexpr (DROP) {
+                            const bool kept = ((j & 1) ? (bits[j >> 1] >> 16) : (bits[j >> 1] & 0xFFFFu)) >= thr;
+                            on = pos & kept;
+                            if constexpr (BITS) onm &= __builtin_amdgcn_ballot_w64(kept);
+                        }
                         zA[j & 1] = fmaf(w4[j], on ? v : 0.f, zA[j & 1]);
-                        if constexpr (BITS) fb[t] = shift_in_bit(fb[t], __builtin_amdgcn_ballot_w64(on));
+                        if constexpr (BITS) fb[t] = shift_in_bit(fb[t], onm);
                         if constexpr (PAIR) {
                             const float v2 = tb - d4[j];                     // the mate: the node-level term with the opposite sign
-                            bool on2 = v2 > 0.f;
-                            if constexpr (DROP) on2 = on2 & (((j & 1) ? (bits2[j >> 1] >> 16) : (bits2[j >> 1] & 0xFFFFu)) >= thr);
+                            const bool pos2 = v2 > 0.f;
+                            bool on2 = pos2;
+                            uint64_t onm2 = BITS ? __builtin_amdgcn_ballot_w64(pos2) : 0ull;
+                            if constexpr (DROP) {
+                                const bool kept2 = ((j & 1) ? (bits2[j >> 1] >> 16) : (bits2[j >> 1] & 0xFFFFu)) >= thr;
+                                on2 = pos2 & kept2;
+                                if constexpr (BITS) onm2 &= __builtin_amdgcn_ballot_w64(kept2);
+                            }
                             zB[j & 1] = fmaf(w4[j], on2 ? v2 : 0.f, zB[j & 1]);
-                            if constexpr (BITS) fb2[PAIR ? t : 0] = shift_in_bit(fb2[PAIR ? t : 0], __builtin_amdgcn_ballot_w64(on2));
+                            if constexpr (BITS) fb2[PAIR ? t : 0] = shift_in_bit(fb2[PAIR ? t : 0], onm2);
                         }
                     }
                     if constexpr (BITS) {
