@@ -796,9 +796,16 @@ __global__ void __launch_bounds__(kT) pack_w1a_bf16x3(const float* __restrict__ 
 // acc <- (acc << 1) | [this lane's bit of `mask`] as ONE vector instruction: v_addc_co_u32 acc, acc + acc + carry-in, the carry-in taken
 // per lane from a 64-bit lane mask (the result of a vector compare).  The scorer's forward epilogue builds its ReLU x dropout mask words
 // with it: one instruction per hidden unit instead of min / shift / or.
+// SALU_MASK: `mask` was produced by a SCALAR instruction (the s_and_b64 of two compare results, in the dropout variants): the two-wait-state
+// rule is about a VECTOR instruction's SGPR result read by the next vector instruction, so no pad is needed -- eight s_nop per epilogue step.
+template <bool SALU_MASK = false>
 __device__ __forceinline__ uint32_t shift_in_bit(uint32_t acc, uint64_t mask) {
     uint32_t out;
     uint64_t carry_out;
+    if constexpr (SALU_MASK) {
+        asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(out), "=s"(carry_out) : "v"(acc), "s"(mask));
+        return out;
+    }
     // (s_nop 1: gfx950 wants two wait states between a vector compare's SGPR result and a vector instruction that reads it as a mask; the
     //  compiler pads its own instructions but does not look inside inline assembly -- without the pad the mask words of a no-dropout
     //  forward came out wrong in a few lanes)
@@ -1212,7 +1219,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
                             if constexpr (BITS) onm &= __builtin_amdgcn_ballot_w64(kept);
                         }
                         zA[j & 1] = fmaf(w4[j], on ? v : 0.f, zA[j & 1]);
-                        if constexpr (BITS) fb[t] = shift_in_bit(fb[t], onm);
+                        if constexpr (BITS) fb[t] = shift_in_bit<DROP>(fb[t], onm);
                         if constexpr (PAIR) {
                             const float v2 = tb - d4[j];                     // the mate: the node-level term with the opposite sign
                             const bool pos2 = v2 > 0.f;
@@ -1224,7 +1231,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) edge_score_bf16x6_kernel(Scor
                                 if constexpr (BITS) onm2 &= __builtin_amdgcn_ballot_w64(kept2);
                             }
                             zB[j & 1] = fmaf(w4[j], on2 ? v2 : 0.f, zB[j & 1]);
-                            if constexpr (BITS) fb2[PAIR ? t : 0] = shift_in_bit(fb2[PAIR ? t : 0], onm2);
+                            if constexpr (BITS) fb2[PAIR ? t : 0] = shift_in_bit<DROP>(fb2[PAIR ? t : 0], onm2);
                         }
                     }
                     if constexpr (BITS) {
