@@ -603,6 +603,15 @@ def run_s5(a, S, rank, world, device, steps=None, warmup=None):
     warm_ei = [None]
 
     def timed_steps(one_step):
+        # the first warm-up step runs with the gate off, i.e. it takes the learned branch whatever the counts say: the caching allocator
+        # grows by the learned backward's ~50 GB there (0.5 s of hipMalloc) and not inside the timed steps when the gate happens to pick
+        # the random branch throughout the warm-up
+        cond = args.conditional
+        args.conditional = False
+        try:
+            one_step()
+        finally:
+            args.conditional = cond
         for _ in range(warmup):
             one_step()
         # set-up, like the CSR build above: the warm-up steps may all take the gate's random branch, and the FIRST learned-branch step then
